@@ -1,0 +1,71 @@
+"""Loader of libdsp_stft_hip.so (ctypes).  There is no fallback: a missing or unloadable library raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdsp_stft_hip.so")
+
+_sz, _int, _vp = C.c_size_t, C.c_int, C.c_void_p
+_f, _d = C.c_float, C.c_double
+
+# every symbol include/dsp_stft.h declares: name -> (restype, argtypes)
+_STFT = [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _int, _int, _int, _int]
+_FRAME = [_vp, _vp, _sz, _sz, _sz, _int]
+_AW = [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _int]
+_AWI = [_vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _int]
+_R2HC = [_vp, _vp, _sz, _sz, _sz, _sz, _int, _sz, _sz, _int]
+_BDEV = [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _int, _int, _int, _int, _vp]
+_BHOST = _BDEV[:-1]
+
+SIGNATURES = {
+    "stft_s": (_int, _STFT), "stft_d": (_int, _STFT),
+    "stft_flt_s": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _f, _f, _int, _int, _int]),
+    "stft_flt_d": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _d, _d, _int, _int, _int]),
+    "fft_power_c": (_int, [_vp, _vp, _sz]), "fft_power_z": (_int, [_vp, _vp, _sz]),
+    "frame_univar_s": (_int, _FRAME), "frame_univar_d": (_int, _FRAME),
+    "frame_univar_c": (_int, _FRAME), "frame_univar_z": (_int, _FRAME),
+    "frame_univar_flt_s": (_int, [_vp, _vp, _sz, _sz, _sz, _f, _f]),
+    "frame_univar_flt_d": (_int, [_vp, _vp, _sz, _sz, _sz, _d, _d]),
+    "frame_univar_flt_c": (_int, [_vp, _vp, _sz, _sz, _sz, _f, _f]),
+    "frame_univar_flt_z": (_int, [_vp, _vp, _sz, _sz, _sz, _d, _d]),
+    "apply_win_s": (_int, _AW), "apply_win_d": (_int, _AW), "apply_win_c": (_int, _AW), "apply_win_z": (_int, _AW),
+    "apply_win_inplace_s": (_int, _AWI), "apply_win_inplace_d": (_int, _AWI),
+    "apply_win_inplace_c": (_int, _AWI), "apply_win_inplace_z": (_int, _AWI),
+    "fft_fftw_r2hc_s": (_int, _R2HC), "fft_fftw_r2hc_d": (_int, _R2HC),
+    "dsp_stft_num_frames": (_sz, [_sz, _sz, _sz, _int]),
+    "dsp_set_device": (_int, [_int]),
+    "dsp_stft_flt_set_mode": (_int, [_int]),
+    "dsp_stft_batch_dev_s": (_int, _BDEV), "dsp_stft_batch_dev_d": (_int, _BDEV),
+    "dsp_stft_flt_batch_dev_s": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _f, _f, _int, _int, _int, _vp]),
+    "dsp_stft_flt_batch_dev_d": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _d, _d, _int, _int, _int, _vp]),
+    "dsp_stft_batch_s": (_int, _BHOST), "dsp_stft_batch_d": (_int, _BHOST),
+    "dsp_fft_power_dev_c": (_int, [_vp, _vp, _sz, _vp]), "dsp_fft_power_dev_z": (_int, [_vp, _vp, _sz, _vp]),
+    "dsp_stft_kernel_family": (_int, [_sz, _sz]),
+    "dsp_stft_force_generic": (_int, [_int]),
+    "dsp_stft_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library with argtypes set.  Raises if it was not built or does not load."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not found: build it with `make -C dsp_amd/csrc` "
+                               "(or __graft_entry__.build()); dsp_amd has no CPU fallback")
+        if not os.environ.get("DSP_AMD_NO_TORCH"):
+            # share one HIP runtime with PyTorch when both live in a process: importing torch first
+            # makes the loader resolve libamdhip64.so.7 to the copy torch already mapped
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
+        handle = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)       # AttributeError here = header and library disagree
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib

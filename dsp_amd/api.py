@@ -1,0 +1,271 @@
+"""Host-side mirror of the reference's operator interface for the STFT path.
+
+Every function here is a thin ctypes call into libdsp_stft_hip.so (include/dsp_stft.h); names,
+argument meaning and error behaviour follow the reference's C entry points (c/stft.c:29-30,
+c/stft_flt.c:29-30, c/frame_univar.c:35-38, c/frame_univar_flt.c:23-26, c/apply_win.c:15-23,
+c/fft.fftw.r2hc.c:20-21, c/fft_power.c:13-14).  A non-zero return code raises DspError; the
+library has already written the reference-style "error in <fn>: ..." line to stderr.
+
+The numpy functions use the host-pointer entry points (copy in, compute on the GPU, copy out).
+The *_dev functions take CUDA/HIP torch tensors and enqueue on torch's current stream.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import lib
+
+
+class DspError(RuntimeError):
+    """A libdsp_stft_hip entry point returned 1."""
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def nextpow2(L):
+    """nfft as the reference's command-line tools derive it (srci/stft.cpp:101-102)."""
+    n = 1
+    while n < L:
+        n *= 2
+    return n
+
+
+def num_frames(N, L, stp, snip_edges=False):
+    """W of stft_s/stft_d (reference c/stft.c:40)."""
+    return int(lib().dsp_stft_num_frames(N, L, stp, int(bool(snip_edges))))
+
+
+def _real_sfx(dtype):
+    if dtype == np.float32:
+        return "s"
+    if dtype == np.float64:
+        return "d"
+    raise TypeError(f"unsupported dtype {dtype}: the reference's data types are float32 and float64")
+
+
+def _any_sfx(dtype):
+    return {"float32": "s", "float64": "d", "complex64": "c", "complex128": "z"}[np.dtype(dtype).name]
+
+
+def _check(rc, name):
+    if rc != 0:
+        raise DspError(f"{name} failed (see stderr)")
+
+
+def stft(x, win, stp=160, snip_edges=False, mn0=False, amp=False, lg=False, nfft=None):
+    """stft_s / stft_d.  x: 1-D signal, win: 1-D window; returns Y[W, nfft//2+1]."""
+    x = np.ascontiguousarray(x)
+    s = _real_sfx(x.dtype)
+    win = np.ascontiguousarray(win, dtype=x.dtype)
+    N, L = x.size, win.size
+    nfft = nextpow2(L) if nfft is None else int(nfft)
+    W = num_frames(N, L, stp, snip_edges)
+    Y = np.empty((W, nfft // 2 + 1), dtype=x.dtype)
+    rc = getattr(lib(), f"stft_{s}")(_p(Y), _p(x), _p(win), N, L, nfft, stp, int(bool(snip_edges)), int(bool(mn0)),
+                                     int(bool(amp)), int(bool(lg)))
+    _check(rc, f"stft_{s}")
+    return Y
+
+
+def stft_batch(x, win, stp=160, snip_edges=False, mn0=False, amp=False, lg=False, nfft=None):
+    """dsp_stft_batch_s / _d.  x: [B, N] (rows may be strided); returns Y[B, W, F]."""
+    x = np.asarray(x)
+    if x.ndim != 2 or x.strides[1] != x.itemsize or (x.shape[0] > 1 and x.strides[0] % x.itemsize):
+        x = np.ascontiguousarray(x)
+    s = _real_sfx(x.dtype)
+    win = np.ascontiguousarray(win, dtype=x.dtype)
+    B, N = x.shape
+    ldx = x.strides[0] // x.itemsize if B > 1 else N
+    L = win.size
+    nfft = nextpow2(L) if nfft is None else int(nfft)
+    W = num_frames(N, L, stp, snip_edges)
+    Y = np.empty((B, W, nfft // 2 + 1), dtype=x.dtype)
+    rc = getattr(lib(), f"dsp_stft_batch_{s}")(_p(Y), _p(x), _p(win), B, N, ldx, L, nfft, stp, int(bool(snip_edges)),
+                                               int(bool(mn0)), int(bool(amp)), int(bool(lg)))
+    _check(rc, f"dsp_stft_batch_{s}")
+    return Y
+
+
+def stft_flt(x, win, W, c0=0.0, stp=160.0, mn0=False, amp=False, lg=False, nfft=None):
+    """stft_flt_s / stft_flt_d.  Returns Y[W, nfft//2+1]."""
+    x = np.ascontiguousarray(x)
+    s = _real_sfx(x.dtype)
+    win = np.ascontiguousarray(win, dtype=x.dtype)
+    N, L = x.size, win.size
+    nfft = nextpow2(L) if nfft is None else int(nfft)
+    Y = np.empty((W, nfft // 2 + 1), dtype=x.dtype)
+    rc = getattr(lib(), f"stft_flt_{s}")(_p(Y), _p(x), _p(win), N, L, W, nfft, c0, stp, int(bool(mn0)), int(bool(amp)),
+                                         int(bool(lg)))
+    _check(rc, f"stft_flt_{s}")
+    return Y
+
+
+def set_flt_mode(intended):
+    """False (default): stft_flt frames as the reference's code computes them; True: as documented."""
+    lib().dsp_stft_flt_set_mode(int(bool(intended)))
+
+
+def force_generic(on):
+    lib().dsp_stft_force_generic(int(bool(on)))
+
+
+def kernel_family(nfft, dtype):
+    return int(lib().dsp_stft_kernel_family(nfft, np.dtype(dtype).itemsize))
+
+
+def frame_univar(x, L, stp, snip_edges=False):
+    """frame_univar_{s,d,c,z}.  Returns Y[W, L]."""
+    x = np.ascontiguousarray(x)
+    s = _any_sfx(x.dtype)
+    W = num_frames(x.size, L, stp, snip_edges)
+    Y = np.empty((W, L), dtype=x.dtype)
+    rc = getattr(lib(), f"frame_univar_{s}")(_p(Y), _p(x), x.size, L, stp, int(bool(snip_edges)))
+    _check(rc, f"frame_univar_{s}")
+    return Y
+
+
+def frame_univar_flt(x, L, W, c0, stp):
+    """frame_univar_flt_{s,d,c,z}.  Returns Y[W, L]."""
+    x = np.ascontiguousarray(x)
+    s = _any_sfx(x.dtype)
+    Y = np.empty((W, L), dtype=x.dtype)
+    rc = getattr(lib(), f"frame_univar_flt_{s}")(_p(Y), _p(x), x.size, L, W, c0, stp)
+    _check(rc, f"frame_univar_flt_{s}")
+    return Y
+
+
+def _dims4(shape):
+    if len(shape) > 4:
+        raise ValueError("tensors have at most 4 dimensions (R, C, S, H)")
+    return tuple(shape) + (1,) * (4 - len(shape))
+
+
+def apply_win(x, win, dim, iscolmajor=False, inplace=False):
+    """apply_win_{s,d,c,z} / apply_win_inplace_*: x .* win with win broadcast along dim.  The logical
+    shape is x.shape; memory order C for row-major, Fortran for column-major."""
+    order = "F" if iscolmajor else "C"
+    x = np.asarray(x)
+    s = _any_sfx(x.dtype)
+    win = np.ascontiguousarray(win, dtype=x.dtype)
+    R, Cc, S, H = _dims4(x.shape)
+    if inplace:
+        if not (x.flags.f_contiguous if iscolmajor else x.flags.c_contiguous):
+            raise ValueError("in-place apply_win needs a contiguous array in the stated major order")
+        rc = getattr(lib(), f"apply_win_inplace_{s}")(_p(x), _p(win), R, Cc, S, H, win.size, dim, int(bool(iscolmajor)))
+        _check(rc, f"apply_win_inplace_{s}")
+        return x
+    xm = np.asarray(x, order=order)
+    Y = np.empty(x.shape, dtype=x.dtype, order=order)
+    rc = getattr(lib(), f"apply_win_{s}")(_p(Y), _p(xm), _p(win), R, Cc, S, H, win.size, dim, int(bool(iscolmajor)))
+    _check(rc, f"apply_win_{s}")
+    return Y
+
+
+def fft_r2hc(x, dim, nfft, iscolmajor=False, sc=False):
+    """fft_fftw_r2hc_s / _d: real FFT along dim, nfft//2+1 complex outputs along dim."""
+    order = "F" if iscolmajor else "C"
+    x = np.asarray(x)
+    s = _real_sfx(x.dtype)
+    xm = np.asarray(x, order=order)
+    R, Cc, S, H = _dims4(x.shape)
+    oshape = list(_dims4(x.shape))
+    oshape[dim] = nfft // 2 + 1
+    oshape = tuple(oshape[: max(x.ndim, dim + 1)])
+    Y = np.empty(oshape, dtype=np.complex64 if x.dtype == np.float32 else np.complex128, order=order)
+    rc = getattr(lib(), f"fft_fftw_r2hc_{s}")(_p(Y), _p(xm), R, Cc, S, H, int(bool(iscolmajor)), dim, nfft, int(bool(sc)))
+    _check(rc, f"fft_fftw_r2hc_{s}")
+    return Y
+
+
+def fft_power(xc):
+    """fft_power_c / _z: |x|^2 element-wise over a complex array."""
+    xc = np.ascontiguousarray(xc)
+    s = {"complex64": "c", "complex128": "z"}[xc.dtype.name]
+    Y = np.empty(xc.shape, dtype=np.float32 if s == "c" else np.float64)
+    rc = getattr(lib(), f"fft_power_{s}")(_p(Y), _p(xc), xc.size)
+    _check(rc, f"fft_power_{s}")
+    return Y
+
+
+# ------------------------------------------------------------------------------------------------
+# device-resident forms (torch tensors are only the carrier of device memory and of the stream)
+# ------------------------------------------------------------------------------------------------
+def _torch_sfx(t):
+    import torch
+    if t.dtype == torch.float32:
+        return "s"
+    if t.dtype == torch.float64:
+        return "d"
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _stream_ptr(t):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def stft_dev(x, win, stp=160, snip_edges=False, mn0=False, amp=False, lg=False, nfft=None, out=None):
+    """dsp_stft_batch_dev_s / _d.  x: device tensor [B, N] (unit stride along N), win: device tensor
+    [L]; returns the device tensor Y[B, W, F].  Enqueued on torch's current stream, not synchronised."""
+    import torch
+    if x.dim() == 1:
+        x = x.unsqueeze(0)
+    if not x.is_cuda or x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("x must be a device tensor [B, N] with unit stride along N")
+    s = _torch_sfx(x)
+    win = win.to(device=x.device, dtype=x.dtype).contiguous()
+    B, N = x.shape
+    ldx = x.stride(0) if B > 1 else N
+    L = win.numel()
+    nfft = nextpow2(L) if nfft is None else int(nfft)
+    W = num_frames(N, L, stp, snip_edges)
+    if out is None:
+        out = torch.empty((B, W, nfft // 2 + 1), dtype=x.dtype, device=x.device)
+    elif tuple(out.shape) != (B, W, nfft // 2 + 1) or not out.is_contiguous() or out.dtype != x.dtype:
+        raise ValueError("out must be a contiguous [B, W, F] tensor of x's dtype")
+    with torch.cuda.device(x.device):
+        rc = getattr(lib(), f"dsp_stft_batch_dev_{s}")(C.c_void_p(out.data_ptr()), C.c_void_p(x.data_ptr()),
+                                                       C.c_void_p(win.data_ptr()), B, N, ldx, L, nfft, stp,
+                                                       int(bool(snip_edges)), int(bool(mn0)), int(bool(amp)),
+                                                       int(bool(lg)), _stream_ptr(x))
+    _check(rc, f"dsp_stft_batch_dev_{s}")
+    return out
+
+
+def stft_flt_dev(x, win, W, c0=0.0, stp=160.0, mn0=False, amp=False, lg=False, nfft=None, out=None):
+    """dsp_stft_flt_batch_dev_s / _d.  x: device tensor [B, N]; returns Y[B, W, F]."""
+    import torch
+    if x.dim() == 1:
+        x = x.unsqueeze(0)
+    if not x.is_cuda or x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("x must be a device tensor [B, N] with unit stride along N")
+    s = _torch_sfx(x)
+    win = win.to(device=x.device, dtype=x.dtype).contiguous()
+    B, N = x.shape
+    ldx = x.stride(0) if B > 1 else N
+    L = win.numel()
+    nfft = nextpow2(L) if nfft is None else int(nfft)
+    if out is None:
+        out = torch.empty((B, W, nfft // 2 + 1), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = getattr(lib(), f"dsp_stft_flt_batch_dev_{s}")(C.c_void_p(out.data_ptr()), C.c_void_p(x.data_ptr()),
+                                                           C.c_void_p(win.data_ptr()), B, N, ldx, L, W, nfft, c0, stp,
+                                                           int(bool(mn0)), int(bool(amp)), int(bool(lg)), _stream_ptr(x))
+    _check(rc, f"dsp_stft_flt_batch_dev_{s}")
+    return out
+
+
+def fft_power_dev(xc, out=None):
+    """dsp_fft_power_dev_c / _z on a complex device tensor."""
+    import torch
+    xc = xc.contiguous()
+    s = {torch.complex64: "c", torch.complex128: "z"}[xc.dtype]
+    if out is None:
+        out = torch.empty(xc.shape, dtype=torch.float32 if s == "c" else torch.float64, device=xc.device)
+    with torch.cuda.device(xc.device):
+        rc = getattr(lib(), f"dsp_fft_power_dev_{s}")(C.c_void_p(out.data_ptr()), C.c_void_p(xc.data_ptr()), xc.numel(),
+                                                      _stream_ptr(xc))
+    _check(rc, f"dsp_fft_power_dev_{s}")
+    return out

@@ -1,0 +1,581 @@
+// C ABI of libdsp_stft_hip.so (declarations and reference citations: include/dsp_stft.h).
+// Host side only: argument checks with the reference's messages, frame descriptors, twiddle-table
+// and workspace caches, host<->device copies for the host-pointer entry points, kernel dispatch.
+#include "stft_common.h"
+#include "../../include/dsp_stft.h"
+
+#include <atomic>
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <list>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+namespace {
+using namespace dsp;
+
+constexpr int MAX_DEV = 64;
+constexpr size_t LDS_LIMIT = 128 * 1024;     // bytes of LDS one generic workgroup may stage
+
+thread_local int tl_device = -1;             // -1: whatever device is current
+std::atomic<int> g_flt_intended{0};
+std::atomic<int> g_force_generic{0};
+
+#define HIPCHK(fn, call)                                                                          \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            fprintf(stderr, "error in %s: hip call failed (%s): %s\n", fn, #call, hipGetErrorString(e_)); \
+            return 1;                                                                             \
+        }                                                                                         \
+    } while (0)
+
+struct TblEntry {
+    std::vector<unsigned char> key;
+    int *dev = nullptr;
+};
+
+struct DevState {
+    std::mutex mu;                            // guards everything below
+    std::map<std::tuple<int, size_t, int>, void *> tw;   // (element size, nfft, full) -> table
+    std::list<TblEntry> tbls;                 // most recently used first
+    // workspace of the host-pointer entry points (one call at a time per device)
+    std::mutex ws_mu;
+    void *ws[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t cap[4] = {0, 0, 0, 0};
+};
+DevState g_dev[MAX_DEV];
+
+int use_device(const char *fn, int &dev)
+{
+    if (tl_device >= 0) { HIPCHK(fn, hipSetDevice(tl_device)); }
+    HIPCHK(fn, hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEV) { fprintf(stderr, "error in %s: hip device index %d out of range\n", fn, dev); return 1; }
+    return 0;
+}
+
+bool is_pow2(size_t n) { return n >= 1 && !(n & (n - 1)); }
+
+// table of W_nfft^k = (cos, -sin)(2 pi k / nfft): k < nfft/2 (full == 0) or k < nfft (full == 1),
+// evaluated in long double and rounded once
+template <typename T>
+int get_twiddles(const char *fn, int dev, size_t nfft, int full, const T *&out)
+{
+    DevState &st = g_dev[dev];
+    std::lock_guard<std::mutex> lk(st.mu);
+    const auto key = std::make_tuple((int)sizeof(T), nfft, full);
+    auto it = st.tw.find(key);
+    if (it != st.tw.end()) { out = static_cast<const T *>(it->second); return 0; }
+    size_t cnt = full ? nfft : nfft / 2;
+    if (cnt == 0) { cnt = 1; }
+    std::vector<T> h(2 * cnt);
+    const long double pi2 = 6.283185307179586476925286766559005768L;
+    for (size_t k = 0; k < cnt; ++k) {
+        // reduce the angle to the first octant so that symmetric entries are exactly symmetric
+        const long double a = pi2 * (long double)k / (long double)nfft;
+        h[2 * k] = (T)cosl(a);
+        h[2 * k + 1] = (T)(-sinl(a));
+    }
+    void *p = nullptr;
+    HIPCHK(fn, hipMalloc(&p, 2 * cnt * sizeof(T)));
+    HIPCHK(fn, hipMemcpy(p, h.data(), 2 * cnt * sizeof(T), hipMemcpyHostToDevice));
+    st.tw[key] = p;
+    out = static_cast<const T *>(p);
+    return 0;
+}
+
+// device copy of a frame table, cached by content key; a table in use is never overwritten
+int get_table(const char *fn, int dev, const std::vector<unsigned char> &key, const std::vector<int> &tbl, const int *&out)
+{
+    DevState &st = g_dev[dev];
+    std::lock_guard<std::mutex> lk(st.mu);
+    for (auto it = st.tbls.begin(); it != st.tbls.end(); ++it) {
+        if (it->key == key) { st.tbls.splice(st.tbls.begin(), st.tbls, it); out = st.tbls.front().dev; return 0; }
+    }
+    if (st.tbls.size() >= 8) {
+        HIPCHK(fn, hipFree(st.tbls.back().dev));      // hipFree waits for the device: no kernel still reads it
+        st.tbls.pop_back();
+    }
+    int *p = nullptr;
+    HIPCHK(fn, hipMalloc((void **)&p, tbl.size() * sizeof(int)));
+    HIPCHK(fn, hipMemcpy(p, tbl.data(), tbl.size() * sizeof(int), hipMemcpyHostToDevice));
+    st.tbls.push_front(TblEntry{key, p});
+    out = p;
+    return 0;
+}
+
+int ws_reserve(const char *fn, DevState &st, int slot, size_t bytes, void *&out)
+{
+    if (bytes == 0) { bytes = 16; }
+    if (st.cap[slot] < bytes) {
+        if (st.ws[slot]) { HIPCHK(fn, hipFree(st.ws[slot])); st.ws[slot] = nullptr; st.cap[slot] = 0; }
+        HIPCHK(fn, hipMalloc(&st.ws[slot], bytes));
+        st.cap[slot] = bytes;
+    }
+    out = st.ws[slot];
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// framing descriptors
+// ------------------------------------------------------------------------------------------------
+// stft framing; reference c/stft.c:40,63-64,100-124
+int stft_desc(const char *fn, FrameDesc &d, size_t B, size_t N, size_t ldx, size_t L, size_t nfft, size_t stp,
+              int snip_edges, int mn0, int amp, int lg, size_t &W)
+{
+    if (L < 1u) { fprintf(stderr, "error in %s: L must be positive\n", fn); return 1; }
+    if (stp < 1u) { fprintf(stderr, "error in %s: stp must be positive\n", fn); return 1; }
+    if (snip_edges && L > N) { fprintf(stderr, "error in %s: L must be < N if snip_edges\n", fn); return 1; }
+    if (nfft < L) { fprintf(stderr, "error in %s: nfft must be >= L\n", fn); return 1; }
+    if (nfft < 2u) { fprintf(stderr, "error in %s: nfft must be >= 2\n", fn); return 1; }
+    W = snip_edges ? 1u + (N - L) / stp : (N + stp / 2u) / stp;
+    if (W > (size_t)INT_MAX || nfft > (size_t)INT_MAX / 4 || B > (size_t)INT_MAX || N > (size_t)LLONG_MAX / 4) {
+        fprintf(stderr, "error in %s: problem size exceeds the supported index range\n", fn); return 1;
+    }
+    d = FrameDesc{};
+    d.N = (long long)N; d.ldx = (long long)ldx;
+    d.ss0 = snip_edges ? 0 : (long long)(stp / 2u) - (long long)(L / 2u);
+    d.rd_shift = 0; d.tbl = nullptr;
+    d.L = (int)L; d.nfft = (int)nfft; d.W = (int)W;
+    d.stp = (int)(stp > (size_t)INT_MAX ? (size_t)INT_MAX : stp);      // stp > INT_MAX implies W <= 1
+    d.edge = 0; d.mn0 = mn0 != 0; d.amp = amp != 0; d.lg = lg != 0; d.B = (int)B;
+    return 0;
+}
+
+template <typename T> T round_away(T x);
+template <> float round_away<float>(float x) { return roundf(x); }
+template <> double round_away<double>(double x) { return round(x); }
+template <typename T> constexpr T type_eps();
+template <> constexpr float type_eps<float>() { return FLT_EPSILON; }
+template <> constexpr double type_eps<double>() { return DBL_EPSILON; }
+
+// stft_flt / frame_univar_flt framing; reference c/stft_flt.c:35-40,57-92, c/frame_univar_flt.c:41-87.
+// The centre is accumulated serially in T, as the reference does, so non-dyadic hops round the same way.
+// as_reference != 0 reproduces the X1 pointer walk of c/stft_flt.c (read start = start - shift once the
+// start is non-negative); otherwise reads start at the frame's own start.
+template <typename T>
+int flt_desc(const char *fn, int dev, FrameDesc &d, size_t B, size_t N, size_t ldx, size_t L, size_t W, size_t nfft, T c0, T stp,
+             int mn0, int amp, int lg, int as_reference, bool check_nfft)
+{
+    if (W > N) { fprintf(stderr, "error in %s: W must be <= N (length X)\n", fn); return 1; }
+    if (L > N) { fprintf(stderr, "error in %s: L must be <= N (length X)\n", fn); return 1; }
+    if (L < 1u) { fprintf(stderr, "error in %s: L must be positive\n", fn); return 1; }
+    if (N < 1u) { fprintf(stderr, "error in %s: N (length X) must be positive\n", fn); return 1; }
+    if (c0 > (T)(N - 1u)) { fprintf(stderr, "error in %s: c0 (center samp of 1st frame) must be < N (length X)\n", fn); return 1; }
+    if (stp < type_eps<T>()) { fprintf(stderr, "error in %s: stp (step size) must be positive\n", fn); return 1; }
+    if (check_nfft) {
+        if (nfft < L) { fprintf(stderr, "error in %s: nfft must be >= L\n", fn); return 1; }
+        if (nfft < 2u) { fprintf(stderr, "error in %s: nfft must be >= 2\n", fn); return 1; }
+    }
+    if (W > (size_t)INT_MAX / 2 || nfft > (size_t)INT_MAX / 4 || B > (size_t)INT_MAX || N > (size_t)INT_MAX) {
+        fprintf(stderr, "error in %s: problem size exceeds the supported index range\n", fn); return 1;
+    }
+    d = FrameDesc{};
+    d.N = (long long)N; d.ldx = (long long)ldx;
+    d.L = (int)L; d.nfft = (int)nfft; d.W = (int)W; d.edge = 1;
+    d.mn0 = mn0 != 0; d.amp = amp != 0; d.lg = lg != 0; d.B = (int)B;
+    d.tbl = nullptr; d.ss0 = 0; d.rd_shift = 0; d.stp = 1;
+    if (W == 0) { return 0; }
+
+    std::vector<int> tbl(2 * W);
+    const int Lpre = (int)(L / 2u), Lpost = (int)L - Lpre - 1;
+    T cc = c0;
+    long long shift = -1;                 // start of the first frame with 0 <= start <= N-1
+    bool uniform = true, left_overlap = false;
+    for (size_t w = 0; w < W; ++w, cc += stp) {
+        const int cs = (int)round_away<T>(cc);
+        const int ss = cs - Lpre, es = cs + Lpost;
+        tbl[2 * w] = ss;
+        if (ss >= 0 && ss <= (int)N - 1 && shift < 0) { shift = ss; }
+        if (ss < 0 && es >= 0) { left_overlap = true; }
+        if (w >= 1 && (long long)ss - tbl[0] != (long long)w * ((long long)tbl[2] - tbl[0])) { uniform = false; }
+    }
+    if (!as_reference || shift < 0) { shift = 0; }
+    for (size_t w = 0; w < W; ++w) { tbl[2 * w + 1] = tbl[2 * w] - (tbl[2 * w] >= 0 ? (int)shift : 0); }
+    const long long hop = (W >= 2) ? (long long)tbl[2] - tbl[0] : 1;
+    if (uniform && hop >= 1 && !(shift != 0 && left_overlap)) {
+        d.ss0 = tbl[0]; d.stp = (int)hop; d.rd_shift = shift;
+        return 0;
+    }
+    std::vector<unsigned char> key(sizeof(size_t) * 3 + 2 * sizeof(T) + 2);
+    unsigned char *k = key.data();
+    memcpy(k, &N, sizeof(size_t)); k += sizeof(size_t);
+    memcpy(k, &L, sizeof(size_t)); k += sizeof(size_t);
+    memcpy(k, &W, sizeof(size_t)); k += sizeof(size_t);
+    memcpy(k, &c0, sizeof(T)); k += sizeof(T);
+    memcpy(k, &stp, sizeof(T)); k += sizeof(T);
+    k[0] = (unsigned char)sizeof(T); k[1] = (unsigned char)(as_reference != 0);
+    return get_table(fn, dev, key, tbl, d.tbl);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused dispatch
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+int family_of(size_t nfft)
+{
+    if (nfft < 2) { return 0; }
+    if (!is_pow2(nfft)) { return 1; }
+    if (nfft == 512 && !g_force_generic.load()) { return 3; }
+    return 2;
+}
+
+template <typename T>
+int run_fused(const char *fn, int dev, T *Yd, const T *Xd, const T *wd, const FrameDesc &d, hipStream_t s)
+{
+    if (d.W == 0 || d.B == 0) { return 0; }
+    const size_t nfft = (size_t)d.nfft;
+    const int fam = family_of<T>(nfft);
+    const T *tw = nullptr;
+    if (fam == 1) {
+        if ((size_t)d.L * sizeof(T) > LDS_LIMIT) { fprintf(stderr, "error in %s: L too large for a non-power-of-two nfft (limit %zu)\n", fn, LDS_LIMIT / sizeof(T)); return 1; }
+        if (get_twiddles<T>(fn, dev, nfft, 1, tw)) { return 1; }
+        HIPCHK(fn, launch_stft_direct<T>(Yd, Xd, wd, tw, d, s));
+        return 0;
+    }
+    if (get_twiddles<T>(fn, dev, nfft, 0, tw)) { return 1; }
+    if (fam == 3 && r512_supported<T>(d)) {
+        HIPCHK(fn, launch_stft_r512<T>(Yd, Xd, wd, tw, d, s));
+        return 0;
+    }
+    if (nfft * sizeof(T) > LDS_LIMIT) { fprintf(stderr, "error in %s: nfft too large (limit %zu)\n", fn, LDS_LIMIT / sizeof(T)); return 1; }
+    HIPCHK(fn, launch_stft_pow2<T>(Yd, Xd, wd, tw, d, s));
+    return 0;
+}
+
+// host-pointer form: copy in, compute on the null stream, copy out (blocking)
+template <typename T>
+int run_fused_host(const char *fn, int dev, T *Y, const T *X, const T *win, FrameDesc &d, size_t x_elems)
+{
+    if (d.W == 0 || d.B == 0) { return 0; }
+    DevState &st = g_dev[dev];
+    std::lock_guard<std::mutex> lk(st.ws_mu);
+    const size_t F = (size_t)d.nfft / 2 + 1;
+    const size_t y_elems = (size_t)d.B * (size_t)d.W * F;
+    void *dx, *dy, *dw;
+    if (ws_reserve(fn, st, 0, x_elems * sizeof(T), dx)) { return 1; }
+    if (ws_reserve(fn, st, 1, y_elems * sizeof(T), dy)) { return 1; }
+    if (ws_reserve(fn, st, 2, (size_t)d.L * sizeof(T), dw)) { return 1; }
+    HIPCHK(fn, hipMemcpy(dx, X, x_elems * sizeof(T), hipMemcpyHostToDevice));
+    HIPCHK(fn, hipMemcpy(dw, win, (size_t)d.L * sizeof(T), hipMemcpyHostToDevice));
+    if (run_fused<T>(fn, dev, (T *)dy, (const T *)dx, (const T *)dw, d, nullptr)) { return 1; }
+    HIPCHK(fn, hipMemcpy(Y, dy, y_elems * sizeof(T), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+template <typename T>
+int stft_host(const char *fn, T *Y, const T *X, const T *win, size_t B, size_t N, size_t ldx, size_t L, size_t nfft, size_t stp,
+              int snip_edges, int mn0, int amp, int lg)
+{
+    FrameDesc d; size_t W;
+    if (stft_desc(fn, d, B, N, ldx, L, nfft, stp, snip_edges, mn0, amp, lg, W)) { return 1; }
+    if (W == 0 || B == 0) { return 0; }
+    int dev;
+    if (use_device(fn, dev)) { return 1; }
+    const size_t x_elems = (B - 1) * ldx + N;
+    return run_fused_host<T>(fn, dev, Y, X, win, d, x_elems);
+}
+
+template <typename T>
+int stft_flt_host(const char *fn, T *Y, const T *X, const T *win, size_t N, size_t L, size_t W, size_t nfft, T c0, T stp,
+                  int mn0, int amp, int lg)
+{
+    // argument checks come before any device work, as in the reference
+    FrameDesc d;
+    int dev = 0;
+    if (W > N || L > N || L < 1u || N < 1u || c0 > (T)(N - 1u) || stp < type_eps<T>() || nfft < L || nfft < 2u || W == 0) {
+        return flt_desc<T>(fn, 0, d, 1, N, N, L, W, nfft, c0, stp, mn0, amp, lg, !g_flt_intended.load(), true);
+    }
+    if (use_device(fn, dev)) { return 1; }
+    if (flt_desc<T>(fn, dev, d, 1, N, N, L, W, nfft, c0, stp, mn0, amp, lg, !g_flt_intended.load(), true)) { return 1; }
+    return run_fused_host<T>(fn, dev, Y, X, win, d, N);
+}
+
+template <typename T>
+int stft_dev(const char *fn, T *Yd, const T *Xd, const T *wd, size_t B, size_t N, size_t ldx, size_t L, size_t nfft, size_t stp,
+             int snip_edges, int mn0, int amp, int lg, void *stream)
+{
+    FrameDesc d; size_t W;
+    if (stft_desc(fn, d, B, N, ldx, L, nfft, stp, snip_edges, mn0, amp, lg, W)) { return 1; }
+    if (W == 0 || B == 0) { return 0; }
+    if (B > 1 && ldx < N) { fprintf(stderr, "error in %s: ldx must be >= N\n", fn); return 1; }
+    if (!Yd || !Xd || !wd) { fprintf(stderr, "error in %s: null device pointer\n", fn); return 1; }
+    int dev;
+    if (use_device(fn, dev)) { return 1; }
+    return run_fused<T>(fn, dev, Yd, Xd, wd, d, (hipStream_t)stream);
+}
+
+template <typename T>
+int stft_flt_dev(const char *fn, T *Yd, const T *Xd, const T *wd, size_t B, size_t N, size_t ldx, size_t L, size_t W, size_t nfft,
+                 T c0, T stp, int mn0, int amp, int lg, void *stream)
+{
+    FrameDesc d;
+    int dev = 0;
+    if (W > N || L > N || L < 1u || N < 1u || c0 > (T)(N - 1u) || stp < type_eps<T>() || nfft < L || nfft < 2u || W == 0 || B == 0) {
+        return flt_desc<T>(fn, 0, d, B, N, ldx, L, W, nfft, c0, stp, mn0, amp, lg, !g_flt_intended.load(), true);
+    }
+    if (B > 1 && ldx < N) { fprintf(stderr, "error in %s: ldx must be >= N\n", fn); return 1; }
+    if (!Yd || !Xd || !wd) { fprintf(stderr, "error in %s: null device pointer\n", fn); return 1; }
+    if (use_device(fn, dev)) { return 1; }
+    if (flt_desc<T>(fn, dev, d, B, N, ldx, L, W, nfft, c0, stp, mn0, amp, lg, !g_flt_intended.load(), true)) { return 1; }
+    return run_fused<T>(fn, dev, Yd, Xd, wd, d, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// unfused entry points
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+int fft_power_host(const char *fn, T *Y, const T *X, size_t N)
+{
+    if (N == 0) { return 0; }
+    int dev;
+    if (use_device(fn, dev)) { return 1; }
+    DevState &st = g_dev[dev];
+    std::lock_guard<std::mutex> lk(st.ws_mu);
+    void *dx, *dy;
+    if (ws_reserve(fn, st, 0, 2 * N * sizeof(T), dx)) { return 1; }
+    if (ws_reserve(fn, st, 1, N * sizeof(T), dy)) { return 1; }
+    HIPCHK(fn, hipMemcpy(dx, X, 2 * N * sizeof(T), hipMemcpyHostToDevice));
+    HIPCHK(fn, launch_fft_power<T>((T *)dy, (const T *)dx, N, nullptr));
+    HIPCHK(fn, hipMemcpy(Y, dy, N * sizeof(T), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+template <typename T>
+int frames_host(const char *fn, T *Y, const T *X, const FrameDesc &d, int E, int dev)
+{
+    if (d.W == 0) { return 0; }
+    DevState &st = g_dev[dev];
+    std::lock_guard<std::mutex> lk(st.ws_mu);
+    void *dx, *dy;
+    const size_t xb = (size_t)d.N * E * sizeof(T), yb = (size_t)d.W * d.L * E * sizeof(T);
+    if (ws_reserve(fn, st, 0, xb, dx)) { return 1; }
+    if (ws_reserve(fn, st, 1, yb, dy)) { return 1; }
+    HIPCHK(fn, hipMemcpy(dx, X, xb, hipMemcpyHostToDevice));
+    HIPCHK(fn, launch_frames<T>((T *)dy, (const T *)dx, d, E, nullptr));
+    HIPCHK(fn, hipMemcpy(Y, dy, yb, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// reference c/frame_univar.c:43-48
+template <typename T>
+int frame_univar_host(const char *fn, T *Y, const T *X, size_t N, size_t L, size_t stp, int snip_edges, int E)
+{
+    if (L < 1u) { fprintf(stderr, "error in %s: L must be positive\n", fn); return 1; }
+    if (stp < 1u) { fprintf(stderr, "error in %s: stp must be positive\n", fn); return 1; }
+    if (snip_edges && L > N) { fprintf(stderr, "error in %s: L must be < N if snip_edges\n", fn); return 1; }
+    FrameDesc d; size_t W;
+    size_t nfft = 2; while (nfft < L) { nfft *= 2; }
+    if (stft_desc(fn, d, 1, N, N, L, nfft, stp, snip_edges, 0, 0, 0, W)) { return 1; }
+    if (W == 0) { return 0; }
+    int dev;
+    if (use_device(fn, dev)) { return 1; }
+    return frames_host<T>(fn, Y, X, d, E, dev);
+}
+
+template <typename T>
+int frame_univar_flt_host(const char *fn, T *Y, const T *X, size_t N, size_t L, size_t W, T c0, T stp, int E)
+{
+    FrameDesc d;
+    int dev = 0;
+    if (W > N || L > N || L < 1u || N < 1u || c0 > (T)(N - 1u) || stp < type_eps<T>() || W == 0) {
+        return flt_desc<T>(fn, 0, d, 1, N, N, L, W, 2, c0, stp, 0, 0, 0, 0, false);
+    }
+    if (use_device(fn, dev)) { return 1; }
+    if (flt_desc<T>(fn, dev, d, 1, N, N, L, W, 2, c0, stp, 0, 0, 0, 0, false)) { return 1; }
+    return frames_host<T>(fn, Y, X, d, E, dev);
+}
+
+// reference c/apply_win.c:28-34
+template <typename T>
+int apply_win_host(const char *fn, T *Y, const T *X1, const T *X2, size_t R, size_t C, size_t S, size_t H, size_t L, size_t dim,
+                   int iscolmajor, int cplx)
+{
+    if (dim > 3u) { fprintf(stderr, "error in %s: dim must be in [0 3]\n", fn); return 1; }
+    if (dim == 0u && R != L) { fprintf(stderr, "error in %s: L (winlength) must equal R (nrows X) for dim=0\n", fn); return 1; }
+    if (dim == 1u && C != L) { fprintf(stderr, "error in %s: L (winlength) must equal C (ncols X) for dim=1\n", fn); return 1; }
+    if (dim == 2u && S != L) { fprintf(stderr, "error in %s: L (winlength) must equal S (nslices X) for dim=2\n", fn); return 1; }
+    if (dim == 3u && H != L) { fprintf(stderr, "error in %s: L (winlength) must equal H (nhyperslices X) for dim=3\n", fn); return 1; }
+    const size_t N = R * C * S * H;
+    if (N == 0) { return 0; }
+    const size_t sz[4] = {R, C, S, H};
+    size_t stride = 1;
+    if (iscolmajor) { for (size_t k = 0; k < dim; ++k) { stride *= sz[k]; } }
+    else { for (size_t k = 3; k > dim; --k) { stride *= sz[k]; } }
+    int dev;
+    if (use_device(fn, dev)) { return 1; }
+    DevState &st = g_dev[dev];
+    std::lock_guard<std::mutex> lk(st.ws_mu);
+    const size_t E = cplx ? 2 : 1;
+    void *dx, *dw;
+    if (ws_reserve(fn, st, 0, N * E * sizeof(T), dx)) { return 1; }
+    if (ws_reserve(fn, st, 2, L * E * sizeof(T), dw)) { return 1; }
+    HIPCHK(fn, hipMemcpy(dx, X1, N * E * sizeof(T), hipMemcpyHostToDevice));
+    HIPCHK(fn, hipMemcpy(dw, X2, L * E * sizeof(T), hipMemcpyHostToDevice));
+    HIPCHK(fn, launch_apply_win<T>((T *)dx, (const T *)dx, (const T *)dw, N, stride, L, cplx, nullptr));
+    HIPCHK(fn, hipMemcpy(Y, dx, N * E * sizeof(T), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// reference c/fft.fftw.r2hc.c:26-39
+template <typename T>
+int r2hc_host(const char *fn, T *Y, const T *X, size_t R, size_t C, size_t S, size_t H, int iscolmajor, size_t dim, size_t nfft, int sc)
+{
+    if (dim > 3u) { fprintf(stderr, "error in %s: dim must be in [0 3]\n", fn); return 1; }
+    const size_t sz[4] = {R, C, S, H};
+    const size_t N = R * C * S * H, Lx = sz[dim], Ly = nfft / 2u + 1u;
+    if (nfft < Lx) { fprintf(stderr, "error in %s: nfft must be >= L (vec length)\n", fn); return 1; }
+    if (nfft == 0u || N == 0u) { return 0; }
+    if (nfft > (size_t)INT_MAX / 4) { fprintf(stderr, "error in %s: nfft exceeds the supported index range\n", fn); return 1; }
+    size_t K = 1;
+    if (iscolmajor) { for (size_t k = 0; k < dim; ++k) { K *= sz[k]; } }
+    else { for (size_t k = 3; k > dim; --k) { K *= sz[k]; } }
+    const size_t V = N / Lx;
+    const int pow2 = (nfft >= 2 && is_pow2(nfft)) ? 1 : 0;
+    if ((pow2 ? nfft : Lx) * sizeof(T) > LDS_LIMIT) { fprintf(stderr, "error in %s: nfft too large (limit %zu)\n", fn, LDS_LIMIT / sizeof(T)); return 1; }
+    int dev;
+    if (use_device(fn, dev)) { return 1; }
+    const T *tw = nullptr;
+    if (get_twiddles<T>(fn, dev, nfft, pow2 ? 0 : 1, tw)) { return 1; }
+    DevState &st = g_dev[dev];
+    std::lock_guard<std::mutex> lk(st.ws_mu);
+    void *dx, *dy;
+    const size_t yb = 2 * V * Ly * sizeof(T);
+    if (ws_reserve(fn, st, 0, N * sizeof(T), dx)) { return 1; }
+    if (ws_reserve(fn, st, 1, yb, dy)) { return 1; }
+    HIPCHK(fn, hipMemcpy(dx, X, N * sizeof(T), hipMemcpyHostToDevice));
+    const T scale = sc ? (T)(1.0 / sqrt((double)(2u * nfft))) : T(1);
+    HIPCHK(fn, launch_r2hc<T>((T *)dy, (const T *)dx, tw, V, K, Lx, nfft, pow2, scale, nullptr));
+    HIPCHK(fn, hipMemcpy(Y, dy, yb, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+int stft_s(float *Y, const float *X1, const float *X2, const size_t N, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg)
+{ return stft_host<float>("stft_s", Y, X1, X2, 1, N, N, L, nfft, stp, snip_edges, mn0, amp, lg); }
+int stft_d(double *Y, const double *X1, const double *X2, const size_t N, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg)
+{ return stft_host<double>("stft_d", Y, X1, X2, 1, N, N, L, nfft, stp, snip_edges, mn0, amp, lg); }
+
+int stft_flt_s(float *Y, const float *X1, const float *X2, const size_t N, const size_t L, const size_t W, const size_t nfft, const float c0, const float stp, const int mn0, const int amp, const int lg)
+{ return stft_flt_host<float>("stft_flt_s", Y, X1, X2, N, L, W, nfft, c0, stp, mn0, amp, lg); }
+int stft_flt_d(double *Y, const double *X1, const double *X2, const size_t N, const size_t L, const size_t W, const size_t nfft, const double c0, const double stp, const int mn0, const int amp, const int lg)
+{ return stft_flt_host<double>("stft_flt_d", Y, X1, X2, N, L, W, nfft, c0, stp, mn0, amp, lg); }
+
+int fft_power_c(float *Y, const float *X, const size_t N) { return fft_power_host<float>("fft_power_c", Y, X, N); }
+int fft_power_z(double *Y, const double *X, const size_t N) { return fft_power_host<double>("fft_power_z", Y, X, N); }
+
+int frame_univar_s(float *Y, const float *X, const size_t N, const size_t L, const size_t stp, const int snip_edges)
+{ return frame_univar_host<float>("frame_univar_s", Y, X, N, L, stp, snip_edges, 1); }
+int frame_univar_d(double *Y, const double *X, const size_t N, const size_t L, const size_t stp, const int snip_edges)
+{ return frame_univar_host<double>("frame_univar_d", Y, X, N, L, stp, snip_edges, 1); }
+int frame_univar_c(float *Y, const float *X, const size_t N, const size_t L, const size_t stp, const int snip_edges)
+{ return frame_univar_host<float>("frame_univar_c", Y, X, N, L, stp, snip_edges, 2); }
+int frame_univar_z(double *Y, const double *X, const size_t N, const size_t L, const size_t stp, const int snip_edges)
+{ return frame_univar_host<double>("frame_univar_z", Y, X, N, L, stp, snip_edges, 2); }
+
+int frame_univar_flt_s(float *Y, const float *X, const size_t N, const size_t L, const size_t W, const float c0, const float stp)
+{ return frame_univar_flt_host<float>("frame_univar_flt_s", Y, X, N, L, W, c0, stp, 1); }
+int frame_univar_flt_d(double *Y, const double *X, const size_t N, const size_t L, const size_t W, const double c0, const double stp)
+{ return frame_univar_flt_host<double>("frame_univar_flt_d", Y, X, N, L, W, c0, stp, 1); }
+int frame_univar_flt_c(float *Y, const float *X, const size_t N, const size_t L, const size_t W, const float c0, const float stp)
+{ return frame_univar_flt_host<float>("frame_univar_flt_c", Y, X, N, L, W, c0, stp, 2); }
+int frame_univar_flt_z(double *Y, const double *X, const size_t N, const size_t L, const size_t W, const double c0, const double stp)
+{ return frame_univar_flt_host<double>("frame_univar_flt_z", Y, X, N, L, W, c0, stp, 2); }
+
+int apply_win_s(float *Y, const float *X1, const float *X2, const size_t R, const size_t C, const size_t S, const size_t H, const size_t L, const size_t dim, const int iscolmajor)
+{ return apply_win_host<float>("apply_win_s", Y, X1, X2, R, C, S, H, L, dim, iscolmajor, 0); }
+int apply_win_d(double *Y, const double *X1, const double *X2, const size_t R, const size_t C, const size_t S, const size_t H, const size_t L, const size_t dim, const int iscolmajor)
+{ return apply_win_host<double>("apply_win_d", Y, X1, X2, R, C, S, H, L, dim, iscolmajor, 0); }
+int apply_win_c(float *Y, const float *X1, const float *X2, const size_t R, const size_t C, const size_t S, const size_t H, const size_t L, const size_t dim, const int iscolmajor)
+{ return apply_win_host<float>("apply_win_c", Y, X1, X2, R, C, S, H, L, dim, iscolmajor, 1); }
+int apply_win_z(double *Y, const double *X1, const double *X2, const size_t R, const size_t C, const size_t S, const size_t H, const size_t L, const size_t dim, const int iscolmajor)
+{ return apply_win_host<double>("apply_win_z", Y, X1, X2, R, C, S, H, L, dim, iscolmajor, 1); }
+int apply_win_inplace_s(float *X1, const float *X2, const size_t R, const size_t C, const size_t S, const size_t H, const size_t L, const size_t dim, const int iscolmajor)
+{ return apply_win_host<float>("apply_win_inplace_s", X1, X1, X2, R, C, S, H, L, dim, iscolmajor, 0); }
+int apply_win_inplace_d(double *X1, const double *X2, const size_t R, const size_t C, const size_t S, const size_t H, const size_t L, const size_t dim, const int iscolmajor)
+{ return apply_win_host<double>("apply_win_inplace_d", X1, X1, X2, R, C, S, H, L, dim, iscolmajor, 0); }
+int apply_win_inplace_c(float *X1, const float *X2, const size_t R, const size_t C, const size_t S, const size_t H, const size_t L, const size_t dim, const int iscolmajor)
+{ return apply_win_host<float>("apply_win_inplace_c", X1, X1, X2, R, C, S, H, L, dim, iscolmajor, 1); }
+int apply_win_inplace_z(double *X1, const double *X2, const size_t R, const size_t C, const size_t S, const size_t H, const size_t L, const size_t dim, const int iscolmajor)
+{ return apply_win_host<double>("apply_win_inplace_z", X1, X1, X2, R, C, S, H, L, dim, iscolmajor, 1); }
+
+int fft_fftw_r2hc_s(float *Y, const float *X, const size_t R, const size_t C, const size_t S, const size_t H, const int iscolmajor, const size_t dim, const size_t nfft, const int sc)
+{ return r2hc_host<float>("fft_fftw_r2hc_s", Y, X, R, C, S, H, iscolmajor, dim, nfft, sc); }
+int fft_fftw_r2hc_d(double *Y, const double *X, const size_t R, const size_t C, const size_t S, const size_t H, const int iscolmajor, const size_t dim, const size_t nfft, const int sc)
+{ return r2hc_host<double>("fft_fftw_r2hc_d", Y, X, R, C, S, H, iscolmajor, dim, nfft, sc); }
+
+// ---------------------------------------- additions ----------------------------------------------
+size_t dsp_stft_num_frames(const size_t N, const size_t L, const size_t stp, const int snip_edges)
+{
+    if (L < 1u || stp < 1u || (snip_edges && L > N)) { return 0u; }
+    return snip_edges ? 1u + (N - L) / stp : (N + stp / 2u) / stp;
+}
+
+int dsp_set_device(const int device)
+{
+    int n = 0;
+    HIPCHK("dsp_set_device", hipGetDeviceCount(&n));
+    if (device < 0 || device >= n || device >= MAX_DEV) { fprintf(stderr, "error in dsp_set_device: device %d not available\n", device); return 1; }
+    tl_device = device;
+    HIPCHK("dsp_set_device", hipSetDevice(device));
+    return 0;
+}
+
+int dsp_stft_flt_set_mode(const int intended) { g_flt_intended.store(intended != 0); return 0; }
+int dsp_stft_force_generic(const int on) { g_force_generic.store(on != 0); return 0; }
+
+int dsp_stft_kernel_family(const size_t nfft, const size_t elem_size)
+{
+    if (elem_size == 4) { return family_of<float>(nfft); }
+    if (elem_size == 8) { return family_of<double>(nfft); }
+    return 0;
+}
+
+int dsp_stft_batch_dev_s(float *Y_dev, const float *X_dev, const float *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, void *stream)
+{ return stft_dev<float>("dsp_stft_batch_dev_s", Y_dev, X_dev, win_dev, B, N, ldx, L, nfft, stp, snip_edges, mn0, amp, lg, stream); }
+int dsp_stft_batch_dev_d(double *Y_dev, const double *X_dev, const double *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, void *stream)
+{ return stft_dev<double>("dsp_stft_batch_dev_d", Y_dev, X_dev, win_dev, B, N, ldx, L, nfft, stp, snip_edges, mn0, amp, lg, stream); }
+
+int dsp_stft_flt_batch_dev_s(float *Y_dev, const float *X_dev, const float *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t W, const size_t nfft, const float c0, const float stp, const int mn0, const int amp, const int lg, void *stream)
+{ return stft_flt_dev<float>("dsp_stft_flt_batch_dev_s", Y_dev, X_dev, win_dev, B, N, ldx, L, W, nfft, c0, stp, mn0, amp, lg, stream); }
+int dsp_stft_flt_batch_dev_d(double *Y_dev, const double *X_dev, const double *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t W, const size_t nfft, const double c0, const double stp, const int mn0, const int amp, const int lg, void *stream)
+{ return stft_flt_dev<double>("dsp_stft_flt_batch_dev_d", Y_dev, X_dev, win_dev, B, N, ldx, L, W, nfft, c0, stp, mn0, amp, lg, stream); }
+
+int dsp_stft_batch_s(float *Y, const float *X, const float *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg)
+{
+    if (B > 1 && ldx < N) { fprintf(stderr, "error in dsp_stft_batch_s: ldx must be >= N\n"); return 1; }
+    return stft_host<float>("dsp_stft_batch_s", Y, X, win, B, N, ldx, L, nfft, stp, snip_edges, mn0, amp, lg);
+}
+int dsp_stft_batch_d(double *Y, const double *X, const double *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg)
+{
+    if (B > 1 && ldx < N) { fprintf(stderr, "error in dsp_stft_batch_d: ldx must be >= N\n"); return 1; }
+    return stft_host<double>("dsp_stft_batch_d", Y, X, win, B, N, ldx, L, nfft, stp, snip_edges, mn0, amp, lg);
+}
+
+int dsp_fft_power_dev_c(float *Y_dev, const float *X_dev, const size_t N, void *stream)
+{
+    int dev;
+    if (use_device("dsp_fft_power_dev_c", dev)) { return 1; }
+    HIPCHK("dsp_fft_power_dev_c", launch_fft_power<float>(Y_dev, X_dev, N, (hipStream_t)stream));
+    return 0;
+}
+int dsp_fft_power_dev_z(double *Y_dev, const double *X_dev, const size_t N, void *stream)
+{
+    int dev;
+    if (use_device("dsp_fft_power_dev_z", dev)) { return 1; }
+    HIPCHK("dsp_fft_power_dev_z", launch_fft_power<double>(Y_dev, X_dev, N, (hipStream_t)stream));
+    return 0;
+}
+
+const char *dsp_stft_version(void) { return "dsp_stft_hip 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,384 @@
+// Fused STFT power-spectrogram kernels for gfx950: framing + window + [mean removal] + real FFT +
+// power + [sqrt] + [log] in one launch (the fused loop of reference c/stft.c:60-96, c/stft_flt.c:63-124).
+//
+// Three families, chosen on the host:
+//   r512   : nfft == 512.  16 lanes per frame, 4 frames per wavefront.  The 512 real samples are
+//            packed as 256 complex points and transformed as 16 x 16: two register-resident
+//            16-point FFTs per lane with one transpose through LDS in between, then the
+//            real-FFT split fused with the power step.  HBM-bound by design: each wave walks a
+//            run of consecutive frames, stages the span of its 4 frames in LDS once and stores
+//            spectrogram rows as whole 256-byte wave stores.
+//   pow2   : any power-of-two nfft.  One 256-thread workgroup per frame, radix-2 passes in LDS.
+//   direct : any other nfft.  O(nfft * L) evaluation of the DFT sum with a table of exact twiddles.
+#include "stft_common.h"
+
+namespace dsp {
+
+// =================================================================================================
+// generic power-of-two family
+// =================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void stft_pow2_kernel(T *__restrict__ Y, const T *__restrict__ X,
+                                                         const T *__restrict__ win, const T *__restrict__ tw,
+                                                         const FrameDesc d)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T *buf = reinterpret_cast<T *>(smem_raw);   // nfft reals, read as M = nfft/2 complex points
+    T *red = buf + d.nfft;                      // 4 partial sums
+    const int tid = threadIdx.x;
+    const int nfft = d.nfft, M = nfft >> 1, F = M + 1, L = d.L;
+    const int lgM = 31 - __clz(M);
+    const long long total = (long long)d.B * d.W;
+
+    for (long long fi = blockIdx.x; fi < total; fi += gridDim.x) {
+        const long long b = fi / d.W;
+        const int w = (int)(fi - b * d.W);
+        long long ss, rdoff;
+        frame_origin(d, w, ss, rdoff);
+        const T *xb = X + b * d.ldx;
+
+        // window the frame into bit-reversed complex order: z_j = v_{2j} + i v_{2j+1}
+        T part = T(0);
+        for (int l = tid; l < nfft; l += 256) {
+            T v = T(0);
+            if (l < L) { v = fetch_sample(xb, d, ss, rdoff, l) * win[l]; part += v; }
+            const int j = l >> 1;
+            const int r = (M > 1) ? (int)(__brev((unsigned)j) >> (32 - lgM)) : 0;
+            buf[2 * r + (l & 1)] = v;
+        }
+        if (d.mn0) {
+            for (int off = 32; off > 0; off >>= 1) { part += __shfl_down(part, off); }
+            if ((tid & 63) == 0) { red[tid >> 6] = part; }
+            __syncthreads();
+            const T mean = (red[0] + red[1] + red[2] + red[3]) / T(L);
+            for (int l = tid; l < L; l += 256) {
+                const int j = l >> 1;
+                const int r = (M > 1) ? (int)(__brev((unsigned)j) >> (32 - lgM)) : 0;
+                buf[2 * r + (l & 1)] -= mean;
+            }
+        }
+        __syncthreads();
+
+        // radix-2 decimation-in-time passes over the M complex points
+        for (int h = 1; h < M; h <<= 1) {
+            const int tstep = M / h;   // W_{2h}^j = W_nfft^{j nfft/(2h)}
+            for (int t = tid; t < (M >> 1); t += 256) {
+                const int j = t & (h - 1);
+                const int i = ((t - j) << 1) + j;
+                const T wr = tw[2 * (j * tstep)], wi = tw[2 * (j * tstep) + 1];
+                const T ar = buf[2 * i], ai = buf[2 * i + 1];
+                const T br = buf[2 * (i + h)], bi = buf[2 * (i + h) + 1];
+                const T tr = br * wr - bi * wi, ti = br * wi + bi * wr;
+                buf[2 * i] = ar + tr; buf[2 * i + 1] = ai + ti;
+                buf[2 * (i + h)] = ar - tr; buf[2 * (i + h) + 1] = ai - ti;
+            }
+            __syncthreads();
+        }
+
+        // real-FFT split fused with power: with A = Z_k + conj Z_{M-k}, B = Z_k - conj Z_{M-k},
+        // X_k = (A - i W^k B)/2 and X_{M-k} = conj((A + i W^k B)/2)
+        T *y = Y + (b * d.W + w) * (long long)F;
+        for (int k = tid; k <= (M >> 1); k += 256) {
+            const int km = (M - k) & (M - 1);
+            const T zr = buf[2 * k], zi = buf[2 * k + 1], mr = buf[2 * km], mi = buf[2 * km + 1];
+            const T wr = tw[2 * k], wi = tw[2 * k + 1];
+            const T ar = zr + mr, ai = zi - mi, br = zr - mr, bi = zi + mi;
+            const T tr = br * wi + bi * wr, ti = bi * wi - br * wr;
+            const T pr = ar + tr, pi = ai + ti, qr = ar - tr, qi = ai - ti;
+            y[k] = power_epilogue(T(0.25) * (pr * pr + pi * pi), d.amp, d.lg);
+            y[M - k] = power_epilogue(T(0.25) * (qr * qr + qi * qi), d.amp, d.lg);
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T>
+hipError_t launch_stft_pow2(T *Y, const T *X, const T *win, const T *tw, const FrameDesc &d, hipStream_t s)
+{
+    const size_t lds = (size_t)d.nfft * sizeof(T) + 64;
+    static size_t granted = 0;
+    if (lds > 48 * 1024 && lds > granted) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&stft_pow2_kernel<T>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { return e; }
+        granted = lds;
+    }
+    const long long total = (long long)d.B * d.W;
+    const int grid = (int)(total < 8192 ? total : 8192);
+    hipLaunchKernelGGL(stft_pow2_kernel<T>, dim3(grid), dim3(256), lds, s, Y, X, win, tw, d);
+    return hipGetLastError();
+}
+
+// =================================================================================================
+// direct family (nfft not a power of two)
+// =================================================================================================
+// tw holds nfft entries (cos, -sin)(2 pi a / nfft).  The power pairing keeps the reference's loops
+// (c/stft.c:80-82): Y[f] = r_f^2, then Y[F-2-j] += Yw[F+j]^2; for even nfft that is r_f^2 + i_f^2,
+// for odd nfft the half-complex slot F+j holds i_{F-1-j}, i.e. Y[f] += i_{f+1}^2 for 1 <= f <= F-2.
+template <typename T>
+__global__ __launch_bounds__(256) void stft_direct_kernel(T *__restrict__ Y, const T *__restrict__ X,
+                                                           const T *__restrict__ win, const T *__restrict__ tw,
+                                                           const FrameDesc d)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T *v = reinterpret_cast<T *>(smem_raw);     // L windowed samples
+    T *red = v + d.L;
+    const int tid = threadIdx.x;
+    const int nfft = d.nfft, F = nfft / 2 + 1, L = d.L, odd = nfft & 1;
+    const long long total = (long long)d.B * d.W;
+
+    for (long long fi = blockIdx.x; fi < total; fi += gridDim.x) {
+        const long long b = fi / d.W;
+        const int w = (int)(fi - b * d.W);
+        long long ss, rdoff;
+        frame_origin(d, w, ss, rdoff);
+        const T *xb = X + b * d.ldx;
+        T part = T(0);
+        for (int l = tid; l < L; l += 256) {
+            const T s = fetch_sample(xb, d, ss, rdoff, l) * win[l];
+            v[l] = s; part += s;
+        }
+        if (d.mn0) {
+            for (int off = 32; off > 0; off >>= 1) { part += __shfl_down(part, off); }
+            if ((tid & 63) == 0) { red[tid >> 6] = part; }
+            __syncthreads();
+            const T mean = (red[0] + red[1] + red[2] + red[3]) / T(L);
+            for (int l = tid; l < L; l += 256) { v[l] -= mean; }
+        }
+        __syncthreads();
+        T *y = Y + (b * d.W + w) * (long long)F;
+        for (int f = tid; f < F; f += 256) {
+            const int k2 = f + odd;
+            int a1 = 0, a2 = 0;
+            double re = 0.0, im = 0.0;
+            for (int l = 0; l < L; ++l) {
+                const double s = (double)v[l];
+                re += s * (double)tw[2 * a1];
+                im += s * (double)tw[2 * a2 + 1];
+                a1 += f; if (a1 >= nfft) { a1 -= nfft; }
+                a2 += k2; if (a2 >= nfft) { a2 -= nfft; }
+            }
+            const T r = (T)re, i = (T)im;
+            T p = r * r;
+            if (f >= 1 && f + 2 <= F) { p += i * i; }
+            y[f] = power_epilogue(p, d.amp, d.lg);
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T>
+hipError_t launch_stft_direct(T *Y, const T *X, const T *win, const T *tw, const FrameDesc &d, hipStream_t s)
+{
+    const size_t lds = (size_t)d.L * sizeof(T) + 64;
+    static size_t granted = 0;
+    if (lds > 48 * 1024 && lds > granted) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&stft_direct_kernel<T>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { return e; }
+        granted = lds;
+    }
+    const long long total = (long long)d.B * d.W;
+    const int grid = (int)(total < 8192 ? total : 8192);
+    hipLaunchKernelGGL(stft_direct_kernel<T>, dim3(grid), dim3(256), lds, s, Y, X, win, tw, d);
+    return hipGetLastError();
+}
+
+template hipError_t launch_stft_pow2<float>(float *, const float *, const float *, const float *, const FrameDesc &, hipStream_t);
+template hipError_t launch_stft_pow2<double>(double *, const double *, const double *, const double *, const FrameDesc &, hipStream_t);
+template hipError_t launch_stft_direct<float>(float *, const float *, const float *, const float *, const FrameDesc &, hipStream_t);
+template hipError_t launch_stft_direct<double>(double *, const double *, const double *, const double *, const FrameDesc &, hipStream_t);
+
+
+// =================================================================================================
+// unfused steps: fft_power, frame_univar[_flt], apply_win, fft_fftw_r2hc
+// =================================================================================================
+
+// reference c/fft_power.c:21 -- Y[n] = re^2 + im^2; pure streaming, 3 elements of traffic per value
+template <typename T>
+__global__ __launch_bounds__(256) void fft_power_kernel(T *__restrict__ Y, const T *__restrict__ X, const size_t N)
+{
+    using T2 = typename vec2<T>::type;
+    const T2 *x2 = reinterpret_cast<const T2 *>(X);
+    for (size_t n = (size_t)blockIdx.x * 256 + threadIdx.x; n < N; n += (size_t)gridDim.x * 256) {
+        const T2 v = x2[n];
+        T y = v.x * v.x;
+        y += v.y * v.y;
+        Y[n] = y;
+    }
+}
+
+template <typename T>
+hipError_t launch_fft_power(T *Y, const T *X, size_t N, hipStream_t s)
+{
+    if (N == 0) { return hipSuccess; }
+    size_t grid = (N + 255) / 256;
+    if (grid > 256 * 32) { grid = 256 * 32; }
+    hipLaunchKernelGGL(fft_power_kernel<T>, dim3((unsigned)grid), dim3(256), 0, s, Y, X, N);
+    return hipGetLastError();
+}
+
+// reference c/frame_univar.c:41-95, c/frame_univar_flt.c:29-91 -- Y[w][l] = X[index(w,l)], E values
+// of T per sample (1 real, 2 complex)
+template <typename T>
+__global__ __launch_bounds__(256) void frames_kernel(T *__restrict__ Y, const T *__restrict__ X, const FrameDesc d, const int E)
+{
+    const long long per_frame = (long long)d.L * E;
+    const long long total = (long long)d.W * per_frame;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int w = (int)(i / per_frame);
+        const int r = (int)(i - (long long)w * per_frame);
+        const int l = r / E, e = r - l * E;
+        long long ss, rdoff;
+        frame_origin(d, w, ss, rdoff);
+        long long n = ss + l;
+        T v = T(0);
+        if (d.edge == 0) {
+            while (n < 0 || n >= d.N) { n = (n < 0) ? -n - 1 : 2 * d.N - 1 - n; }
+            v = X[n * E + e];
+        } else if (n >= 0 && n < d.N) {
+            v = X[(n - rdoff) * E + e];
+        }
+        Y[i] = v;
+    }
+}
+
+template <typename T>
+hipError_t launch_frames(T *Y, const T *X, const FrameDesc &d, int E, hipStream_t s)
+{
+    const long long total = (long long)d.W * d.L * E;
+    if (total == 0) { return hipSuccess; }
+    long long grid = (total + 255) / 256;
+    if (grid > 256 * 32) { grid = 256 * 32; }
+    hipLaunchKernelGGL(frames_kernel<T>, dim3((unsigned)grid), dim3(256), 0, s, Y, X, d, E);
+    return hipGetLastError();
+}
+
+// reference c/apply_win.c:26-108 -- Y[n] = X1[n] * X2[(n / stride_dim) % len_dim]
+template <typename T>
+__global__ __launch_bounds__(256) void apply_win_kernel(T *Y, const T *X1, const T *__restrict__ X2,
+                                                         const size_t N, const size_t stride_dim, const size_t len_dim,
+                                                         const int cplx)
+{
+    using T2 = typename vec2<T>::type;
+    for (size_t n = (size_t)blockIdx.x * 256 + threadIdx.x; n < N; n += (size_t)gridDim.x * 256) {
+        const size_t l = (n / stride_dim) % len_dim;
+        if (cplx) {
+            const T2 a = reinterpret_cast<const T2 *>(X1)[n], b = reinterpret_cast<const T2 *>(X2)[l];
+            T2 o;
+            o.x = a.x * b.x - a.y * b.y;
+            o.y = a.x * b.y + a.y * b.x;
+            reinterpret_cast<T2 *>(Y)[n] = o;
+        } else {
+            Y[n] = X1[n] * X2[l];
+        }
+    }
+}
+
+template <typename T>
+hipError_t launch_apply_win(T *Y, const T *X1, const T *X2, size_t N, size_t stride_dim, size_t len_dim, int cplx, hipStream_t s)
+{
+    if (N == 0) { return hipSuccess; }
+    size_t grid = (N + 255) / 256;
+    if (grid > 256 * 32) { grid = 256 * 32; }
+    hipLaunchKernelGGL(apply_win_kernel<T>, dim3((unsigned)grid), dim3(256), 0, s, Y, X1, X2, N, stride_dim, len_dim, cplx);
+    return hipGetLastError();
+}
+
+// reference c/fft.fftw.r2hc.c:24-109 -- real FFT of V vectors of length Lx (element stride K, vector
+// v = (o, i): X + o K Lx + i), zero-padded to nfft, output nfft/2+1 interleaved complex values with
+// the same stride.  pow2 != 0: radix-2 in LDS (tw: nfft/2 entries); else direct sum (tw: nfft entries).
+template <typename T>
+__global__ __launch_bounds__(256) void r2hc_kernel(T *__restrict__ Y, const T *__restrict__ X, const T *__restrict__ tw,
+                                                    const size_t V, const size_t K, const size_t Lx, const int nfft,
+                                                    const int pow2, const T scale)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T *buf = reinterpret_cast<T *>(smem_raw);
+    const int tid = threadIdx.x;
+    const int M = nfft >> 1, Ly = nfft / 2 + 1;
+    for (size_t v = blockIdx.x; v < V; v += gridDim.x) {
+        const size_t o = v / K, i = v - o * K;
+        const T *x = X + o * K * Lx + i;
+        T *y = Y + 2 * (o * K * (size_t)Ly + i);
+        if (pow2) {
+            const int lgM = 31 - __clz(M);
+            for (int l = tid; l < nfft; l += 256) {
+                const T s = ((size_t)l < Lx) ? x[(size_t)l * K] : T(0);
+                const int j = l >> 1;
+                const int r = (M > 1) ? (int)(__brev((unsigned)j) >> (32 - lgM)) : 0;
+                buf[2 * r + (l & 1)] = s;
+            }
+            __syncthreads();
+            for (int h = 1; h < M; h <<= 1) {
+                const int tstep = M / h;
+                for (int t = tid; t < (M >> 1); t += 256) {
+                    const int j = t & (h - 1);
+                    const int a = ((t - j) << 1) + j;
+                    const T wr = tw[2 * (j * tstep)], wi = tw[2 * (j * tstep) + 1];
+                    const T ar = buf[2 * a], ai = buf[2 * a + 1];
+                    const T br = buf[2 * (a + h)], bi = buf[2 * (a + h) + 1];
+                    const T tr = br * wr - bi * wi, ti = br * wi + bi * wr;
+                    buf[2 * a] = ar + tr; buf[2 * a + 1] = ai + ti;
+                    buf[2 * (a + h)] = ar - tr; buf[2 * (a + h) + 1] = ai - ti;
+                }
+                __syncthreads();
+            }
+            for (int k = tid; k <= (M >> 1); k += 256) {
+                const int km = (M - k) & (M - 1);
+                const T zr = buf[2 * k], zi = buf[2 * k + 1], mr = buf[2 * km], mi = buf[2 * km + 1];
+                const T wr = tw[2 * k], wi = tw[2 * k + 1];
+                const T ar = zr + mr, ai = zi - mi, br = zr - mr, bi = zi + mi;
+                const T tr = br * wi + bi * wr, ti = bi * wi - br * wr;
+                const T h = T(0.5) * scale;
+                T xr = h * (ar + tr), xi = h * (ai + ti), ur = h * (ar - tr), ui = -h * (ai - ti);
+                if (k == 0) { xi = T(0); ui = T(0); }       // imag(DC) = imag(Nyquist) = 0
+                y[2 * (size_t)k * K] = xr; y[2 * (size_t)k * K + 1] = xi;
+                y[2 * (size_t)(M - k) * K] = ur; y[2 * (size_t)(M - k) * K + 1] = ui;
+            }
+        } else {
+            for (int l = tid; (size_t)l < Lx; l += 256) { buf[l] = x[(size_t)l * K]; }
+            __syncthreads();
+            for (int k = tid; k < Ly; k += 256) {
+                int a = 0;
+                double re = 0.0, im = 0.0;
+                for (int l = 0; (size_t)l < Lx; ++l) {
+                    const double s = (double)buf[l];
+                    re += s * (double)tw[2 * a];
+                    im += s * (double)tw[2 * a + 1];
+                    a += k; if (a >= nfft) { a -= nfft; }
+                }
+                if (k == 0 || 2 * k == nfft) { im = 0.0; }
+                y[2 * (size_t)k * K] = (T)re * scale; y[2 * (size_t)k * K + 1] = (T)im * scale;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T>
+hipError_t launch_r2hc(T *Y, const T *X, const T *tw, size_t V, size_t K, size_t Lx, size_t nfft, int pow2, T scale, hipStream_t s)
+{
+    if (V == 0) { return hipSuccess; }
+    const size_t lds = (pow2 ? nfft : Lx) * sizeof(T) + 64;
+    static size_t granted = 0;
+    if (lds > 48 * 1024 && lds > granted) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&r2hc_kernel<T>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { return e; }
+        granted = lds;
+    }
+    const size_t grid = V < 8192 ? V : 8192;
+    hipLaunchKernelGGL(r2hc_kernel<T>, dim3((unsigned)grid), dim3(256), lds, s, Y, X, tw, V, K, Lx, (int)nfft, pow2, scale);
+    return hipGetLastError();
+}
+
+template hipError_t launch_fft_power<float>(float *, const float *, size_t, hipStream_t);
+template hipError_t launch_fft_power<double>(double *, const double *, size_t, hipStream_t);
+template hipError_t launch_frames<float>(float *, const float *, const FrameDesc &, int, hipStream_t);
+template hipError_t launch_frames<double>(double *, const double *, const FrameDesc &, int, hipStream_t);
+template hipError_t launch_apply_win<float>(float *, const float *, const float *, size_t, size_t, size_t, int, hipStream_t);
+template hipError_t launch_apply_win<double>(double *, const double *, const double *, size_t, size_t, size_t, int, hipStream_t);
+template hipError_t launch_r2hc<float>(float *, const float *, const float *, size_t, size_t, size_t, size_t, int, float, hipStream_t);
+template hipError_t launch_r2hc<double>(double *, const double *, const double *, size_t, size_t, size_t, size_t, int, double, hipStream_t);
+}  // namespace dsp

@@ -1,0 +1,80 @@
+// Shared declarations of the HIP STFT library (host + device).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+
+namespace dsp {
+
+// Where frame w of a signal starts and how its samples are fetched.
+//   uniform mode (tbl == nullptr): start ss_w = ss0 + w*stp
+//   table mode  (tbl != nullptr):  ss_w = tbl[2w], read start rd_w = tbl[2w+1]
+// edge == 0: sample index n = ss_w + l is reflected into [0,N) (reference c/stft.c:113)
+// edge == 1: value is 0 unless 0 <= n < N, else X[n - (ss_w - rd_w)]  (reference c/stft_flt.c:66-88)
+struct FrameDesc {
+    long long N;         // samples per signal
+    long long ldx;       // elements between the starts of consecutive signals
+    long long ss0;       // uniform mode: start sample of frame 0
+    long long rd_shift;  // uniform mode, edge == 1: ss_w - rd_w (the same for every frame)
+    const int *tbl;      // table mode: 2 ints per frame
+    int L;               // window length
+    int nfft;            // transform length
+    int W;               // frames per signal
+    int stp;             // uniform mode: hop in samples
+    int edge;
+    int mn0, amp, lg;
+    int B;               // signals
+};
+
+template <typename T>
+__device__ __forceinline__ T fetch_sample(const T *__restrict__ xb, const FrameDesc &d, long long ss, long long rdoff, int l)
+{
+    long long n = ss + l;
+    if (d.edge == 0) {
+        while (n < 0 || n >= d.N) { n = (n < 0) ? -n - 1 : 2 * d.N - 1 - n; }
+        return xb[n];
+    }
+    return (n >= 0 && n < d.N) ? xb[n - rdoff] : T(0);
+}
+
+__device__ __forceinline__ void frame_origin(const FrameDesc &d, int w, long long &ss, long long &rdoff)
+{
+    if (d.tbl) { ss = d.tbl[2 * w]; rdoff = ss - (long long)d.tbl[2 * w + 1]; }
+    else { ss = d.ss0 + (long long)w * d.stp; rdoff = d.rd_shift; }
+}
+
+// sqrt / log epilogue of the power value (reference c/stft.c:86-95)
+template <typename T>
+__device__ __forceinline__ T power_epilogue(T p, int amp, int lg)
+{
+    if (amp) { p = sqrt(p); }
+    if (lg) { p = log(p); }
+    return p;
+}
+
+template <typename T> struct vec2;
+template <> struct vec2<float> { using type = float2; };
+template <> struct vec2<double> { using type = double2; };
+
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- launchers (stft_kernels.hip) -------------------------------------------------------------
+// tw: device table of W_nfft^k = (cos, -sin)(2 pi k / nfft), k < nfft/2 (power-of-two families) or
+//     k < nfft (direct family), as interleaved pairs of T.
+template <typename T> hipError_t launch_stft_pow2(T *Y, const T *X, const T *win, const T *tw, const FrameDesc &d, hipStream_t s);
+template <typename T> hipError_t launch_stft_direct(T *Y, const T *X, const T *win, const T *tw, const FrameDesc &d, hipStream_t s);
+template <typename T> hipError_t launch_stft_r512(T *Y, const T *X, const T *win, const T *tw, const FrameDesc &d, hipStream_t s);
+template <typename T> bool r512_supported(const FrameDesc &d);
+
+// ---- unfused kernels (unfused_kernels.hip) ----------------------------------------------------
+template <typename T> hipError_t launch_fft_power(T *Y, const T *X, size_t N, hipStream_t s);
+template <typename T> hipError_t launch_frames(T *Y, const T *X, const FrameDesc &d, int E, hipStream_t s);
+template <typename T> hipError_t launch_apply_win(T *Y, const T *X1, const T *X2, size_t N, size_t stride_dim, size_t len_dim, int cplx, hipStream_t s);
+template <typename T> hipError_t launch_r2hc(T *Y, const T *X, const T *tw, size_t V, size_t K, size_t Lx, size_t nfft, int pow2, T scale, hipStream_t s);
+
+}  // namespace dsp

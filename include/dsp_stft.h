@@ -1,0 +1,124 @@
+/*
+ * dsp_stft.h -- C ABI of libdsp_stft_hip.so: the STFT power-spectrogram path of the dsp library
+ * (framing, windowing, real FFT, power) computed by hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * Part 1 keeps the reference's entry points byte for byte (names, argument order and meaning,
+ * 0 / 1 return code, one "error in <fn>: ..." line on stderr).  All pointers in part 1 are HOST
+ * pointers; results are in Y when the call returns.  The reference has no headers: each of its
+ * command-line tools #includes the .c file that holds these declarations, so the citation on each
+ * block is the declaration this one replaces.
+ *
+ * Part 2 is additional: batched and device-resident forms of the same computation, plus set-up and
+ * diagnostics.  Nothing in part 2 exists in the reference.
+ *
+ * There is no CPU fallback: when no HIP device is usable every compute entry point returns 1 with an
+ * "error in <fn>: hip..." line.
+ */
+#ifndef DSP_STFT_H
+#define DSP_STFT_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ===================== Part 1: the reference's entry points (host pointers) ===================== */
+
+/* reference c/stft.c:29-30.  Y[W][F] (frame-major), F = nfft/2+1,
+ * W = snip_edges ? 1+(N-L)/stp : (N+stp/2)/stp.  mn0: subtract the frame mean after windowing;
+ * amp: sqrt of power; lg: natural log of the result.  Differences from the reference, both where it
+ * has undefined behaviour: nfft < L and nfft < 2 are rejected with return 1. */
+int stft_s (float *Y, const float *X1, const float *X2, const size_t N, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg);
+int stft_d (double *Y, const double *X1, const double *X2, const size_t N, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg);
+
+/* reference c/stft_flt.c:29-30.  W frames centred at round(c0 + w*stp) (centre accumulated in the
+ * data type, rounding half away from zero), zeros outside [0,N-1].  The default framing reproduces
+ * what the reference's code actually computes (see dsp_stft_flt_set_mode). */
+int stft_flt_s (float *Y, const float *X1, const float *X2, const size_t N, const size_t L, const size_t W, const size_t nfft, const float c0, const float stp, const int mn0, const int amp, const int lg);
+int stft_flt_d (double *Y, const double *X1, const double *X2, const size_t N, const size_t L, const size_t W, const size_t nfft, const double c0, const double stp, const int mn0, const int amp, const int lg);
+
+/* reference c/fft_power.c:13-14.  Y[n] = re^2 + im^2 over N interleaved complex values. */
+int fft_power_c (float *Y, const float *X, const size_t N);
+int fft_power_z (double *Y, const double *X, const size_t N);
+
+/* reference c/frame_univar.c:35-38.  Y[W][L] frames of X with the stft framing (edge reflection). */
+int frame_univar_s (float *Y, const float *X, const size_t N, const size_t L, const size_t stp, const int snip_edges);
+int frame_univar_d (double *Y, const double *X, const size_t N, const size_t L, const size_t stp, const int snip_edges);
+int frame_univar_c (float *Y, const float *X, const size_t N, const size_t L, const size_t stp, const int snip_edges);
+int frame_univar_z (double *Y, const double *X, const size_t N, const size_t L, const size_t stp, const int snip_edges);
+
+/* reference c/frame_univar_flt.c:23-26.  Y[W][L] frames with the _flt framing (zeros outside X). */
+int frame_univar_flt_s (float *Y, const float *X, const size_t N, const size_t L, const size_t W, const float c0, const float stp);
+int frame_univar_flt_d (double *Y, const double *X, const size_t N, const size_t L, const size_t W, const double c0, const double stp);
+int frame_univar_flt_c (float *Y, const float *X, const size_t N, const size_t L, const size_t W, const float c0, const float stp);
+int frame_univar_flt_z (double *Y, const double *X, const size_t N, const size_t L, const size_t W, const double c0, const double stp);
+
+/* reference c/apply_win.c:15-23.  Y = X1 .* X2, X2 (length L) broadcast along dim of the
+ * R x C x S x H tensor X1, row- or column-major; the _c/_z forms multiply complex by complex.
+ * The map is index-exact (X2 indexed by the coordinate along dim); the reference's strided branch
+ * walks X2 past its end for tensors of more than two non-singleton axes, which is not reproduced. */
+int apply_win_s (float *Y, const float *X1, const float *X2, const size_t R, const size_t C, const size_t S, const size_t H, const size_t L, const size_t dim, const int iscolmajor);
+int apply_win_d (double *Y, const double *X1, const double *X2, const size_t R, const size_t C, const size_t S, const size_t H, const size_t L, const size_t dim, const int iscolmajor);
+int apply_win_c (float *Y, const float *X1, const float *X2, const size_t R, const size_t C, const size_t S, const size_t H, const size_t L, const size_t dim, const int iscolmajor);
+int apply_win_z (double *Y, const double *X1, const double *X2, const size_t R, const size_t C, const size_t S, const size_t H, const size_t L, const size_t dim, const int iscolmajor);
+int apply_win_inplace_s (float *X1, const float *X2, const size_t R, const size_t C, const size_t S, const size_t H, const size_t L, const size_t dim, const int iscolmajor);
+int apply_win_inplace_d (double *X1, const double *X2, const size_t R, const size_t C, const size_t S, const size_t H, const size_t L, const size_t dim, const int iscolmajor);
+int apply_win_inplace_c (float *X1, const float *X2, const size_t R, const size_t C, const size_t S, const size_t H, const size_t L, const size_t dim, const int iscolmajor);
+int apply_win_inplace_z (double *X1, const double *X2, const size_t R, const size_t C, const size_t S, const size_t H, const size_t L, const size_t dim, const int iscolmajor);
+
+/* reference c/fft.fftw.r2hc.c:20-21.  Real FFT of every vector along dim, zero-padded to nfft;
+ * Y has nfft/2+1 interleaved complex values along dim, imag(DC) = imag(Nyquist) = 0.  sc scales
+ * by 1/sqrt(2 nfft).  (The reference's single-vector branch and its sc loop read/write out of
+ * bounds, c/fft.fftw.r2hc.c:56-59,101-105; the mathematically intended result is returned.) */
+int fft_fftw_r2hc_s (float *Y, const float *X, const size_t R, const size_t C, const size_t S, const size_t H, const int iscolmajor, const size_t dim, const size_t nfft, const int sc);
+int fft_fftw_r2hc_d (double *Y, const double *X, const size_t R, const size_t C, const size_t S, const size_t H, const int iscolmajor, const size_t dim, const size_t nfft, const int sc);
+
+
+/* ===================== Part 2: additions (no counterpart in the reference) ===================== */
+
+/* Number of frames of stft_s/_d (reference formula, c/stft.c:40); 0 when the arguments are invalid. */
+size_t dsp_stft_num_frames (const size_t N, const size_t L, const size_t stp, const int snip_edges);
+
+/* Selects the HIP device used by the calling thread's later calls (default: the current device). */
+int dsp_set_device (const int device);
+
+/* stft_flt framing: 0 (default) = what the reference's code computes: once frames stop overlapping
+ * the left edge every frame is read `shift` samples early, shift = start of the first frame whose
+ * start is >= 0 (c/stft_flt.c:72-82 never advances X1 to that start); 1 = the documented framing of
+ * c/window_univar_flt.c / c/frame_univar_flt.c.  Both agree when that first start is 0. */
+int dsp_stft_flt_set_mode (const int intended);
+
+/* Batched, DEVICE-resident STFT: B signals of N samples, signal b at X_dev + b*ldx; one window;
+ * output Y_dev[b][W][F] dense.  Pointers are device pointers; the work is enqueued on `stream`
+ * (a hipStream_t, NULL = default stream) and NOT synchronised.  Flags as stft_s. */
+int dsp_stft_batch_dev_s (float *Y_dev, const float *X_dev, const float *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, void *stream);
+int dsp_stft_batch_dev_d (double *Y_dev, const double *X_dev, const double *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, void *stream);
+
+/* Batched, device-resident stft_flt (same conventions; W frames per signal). */
+int dsp_stft_flt_batch_dev_s (float *Y_dev, const float *X_dev, const float *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t W, const size_t nfft, const float c0, const float stp, const int mn0, const int amp, const int lg, void *stream);
+int dsp_stft_flt_batch_dev_d (double *Y_dev, const double *X_dev, const double *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t W, const size_t nfft, const double c0, const double stp, const int mn0, const int amp, const int lg, void *stream);
+
+/* Batched host-pointer forms: X[b*ldx + n], Y[b][W][F]; copies in, computes, copies out. */
+int dsp_stft_batch_s (float *Y, const float *X, const float *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg);
+int dsp_stft_batch_d (double *Y, const double *X, const double *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg);
+
+/* Device-resident fft_power over N interleaved complex values, enqueued on `stream`. */
+int dsp_fft_power_dev_c (float *Y_dev, const float *X_dev, const size_t N, void *stream);
+int dsp_fft_power_dev_z (double *Y_dev, const double *X_dev, const size_t N, void *stream);
+
+/* Which kernel family the fused path would use for (nfft, element size 4 or 8):
+ * 0 = none (invalid), 1 = direct DFT (nfft not a power of two), 2 = generic power-of-two,
+ * 3 = register-resident 512-point.  For tests and benchmarks. */
+int dsp_stft_kernel_family (const size_t nfft, const size_t elem_size);
+
+/* Forces the generic kernel family (2, or 1 for non-powers-of-two) when on != 0; for A/B tests. */
+int dsp_stft_force_generic (const int on);
+
+/* Library version string. */
+const char *dsp_stft_version (void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

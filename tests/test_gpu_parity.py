@@ -1,0 +1,402 @@
+"""GPU parity tests: every entry point of libdsp_stft_hip.so, called through the C ABI, against the CPU
+oracle on the same seeded inputs, and against the fixtures made from executed reference code.
+
+Tolerance of the path (stated once, used everywhere): per-frame-normalised max error
+    max_f |Y - Yref| / max_f |Yref|  <=  1e-5 (float32), 1e-12 (float64)
+for power and amplitude outputs.  Log outputs are compared after exp() with the same bound (an
+element-wise bound in the log domain is meaningless on bins that are 1e-12 of the frame maximum)
+and must have -inf exactly where the oracle has it.  Copies (framing) are bit-exact.
+"""
+import numpy as np
+import pytest
+
+from conftest import TOL, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def D():
+    import dsp_amd
+    return dsp_amd
+
+
+def check_spec(O, Y, Yref, amp=False, lg=False, tol=None):
+    assert Y.shape == Yref.shape and Y.dtype == Yref.dtype
+    tol = TOL[Y.dtype] if tol is None else tol
+    if lg:
+        assert np.array_equal(np.isneginf(Y), np.isneginf(Yref))
+        with np.errstate(over="ignore"):
+            Y = np.exp(Y.astype(np.float64))
+            Yref = np.exp(Yref.astype(np.float64))
+    assert np.all(np.isfinite(Y) == np.isfinite(Yref))
+    Y = np.where(np.isfinite(Y), Y, 0)
+    Yref = np.where(np.isfinite(Yref), Yref, 0)
+    err = O.normalised_err(Y, Yref)
+    assert err <= tol, f"normalised error {err:.3e} > {tol:.1e}"
+    return err
+
+
+def signal(seed, N, dt):
+    return np.random.default_rng(seed).standard_normal(N).astype(dt)
+
+
+CASES = [
+    # N, L, stp, nfft
+    (2000, 400, 160, 512),
+    (16000, 400, 160, 512),
+    (300, 400, 160, 512),        # N < L: repeated reflection
+    (2000, 401, 160, 512),       # odd L
+    (2001, 400, 161, 512),       # odd hop: unaligned frame starts
+    (9000, 512, 700, 512),       # hop > nfft
+    (3000, 300, 100, 512),       # nfft > nextpow2(L) is allowed by the C API
+    (2000, 1, 7, 512),
+    (2000, 64, 100, 64),
+    (400, 400, 160, 512),
+    (5000, 400, 160, 1024),
+    (9000, 4096, 1024, 4096),
+    (1000, 30, 10, 32),
+    (100, 2, 1, 2),
+    (500, 3, 2, 4),
+    (2000, 300, 160, 300),       # even, not a power of two: direct family
+    (600, 45, 20, 45),           # odd nfft: the reference's own pairing of the half-complex array
+    (40000, 16384, 5000, 16384),
+]
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "N%d_L%d_s%d_n%d" % c)
+def test_stft_matches_oracle(O, D, dt, case):
+    N, L, stp, nfft = case
+    x = signal(hash(case) % 1000, N, dt)
+    win = (np.hanning(L) + 0.1).astype(dt) if L > 2 else np.ones(L, dt)
+    for snip in (0, 1):
+        if snip and L > N:
+            continue
+        rc, Yref = O.stft(x, win, stp, nfft, snip)
+        assert rc == 0
+        Y = D.stft(x, win, stp, bool(snip), nfft=nfft)
+        check_spec(O, Y, Yref)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("mn0,amp,lg", [(1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 1), (0, 1, 1)])
+def test_stft_flags(O, D, dt, generic, mn0, amp, lg):
+    x = signal(5, 16000, dt) + dt(0.3)
+    win = D.hann(400, dt)
+    D.force_generic(generic)
+    try:
+        for snip in (0, 1):
+            rc, Yref = O.stft(x, win, 160, 512, snip, mn0, amp, lg)
+            Y = D.stft(x, win, 160, bool(snip), bool(mn0), bool(amp), bool(lg))
+            check_spec(O, Y, Yref, amp, lg)
+    finally:
+        D.force_generic(False)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_both_512_families_agree_with_oracle(O, D, dt):
+    """nfft 512 has two kernel families; each must meet the bound on its own (W not a multiple of 4,
+    a hop above the span-staging limit, an odd hop)."""
+    for (N, L, stp) in [(7013, 400, 160), (7013, 512, 33), (30000, 320, 1500), (1900, 400, 160), (700, 400, 160)]:
+        x = signal(N, N, dt)
+        win = D.povey(L, dt)
+        rc, Yref = O.stft(x, win, stp, 512, 0)
+        for generic in (False, True):
+            D.force_generic(generic)
+            try:
+                Y = D.stft(x, win, stp, nfft=512)
+            finally:
+                D.force_generic(False)
+            check_spec(O, Y, Yref)
+
+
+@pytest.mark.parametrize("tag", ["s", "d"])
+def test_stft_against_reference_fixtures(O, D, tag):
+    """Fixtures hold what the reference's own frame_univar -> apply_win -> FFT -> fft_power returned."""
+    g = load_golden(f"ref_chain_{tag}.npz")
+    for name in ["base", "short_multifold", "oddL", "hop_gt_L", "N_eq_L", "nfft4096", "nfft_gt_pow2", "tiny"]:
+        x, win = g[f"{name}.x"], g[f"{name}.win"]
+        N, L, stp, nfft = (int(v) for v in g[f"{name}.params"])
+        for snip in (0, 1):
+            key = f"{name}.snip{snip}.power"
+            if key not in g:
+                continue
+            Y = D.stft(x, win, stp, bool(snip), nfft=nfft)
+            check_spec(O, Y, g[key])
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+@pytest.mark.parametrize("intended", [False, True])
+def test_stft_flt_matches_oracle(O, D, dt, intended):
+    x = signal(21, 3000, dt)
+    win = D.povey(400, dt)
+    D.set_flt_mode(intended)
+    try:
+        for (c0, stp, W, flags) in [(0.0, 160.0, 18, (0, 0, 0)), (300.0, 160.0, 12, (1, 0, 0)), (-50.0, 160.0, 14, (0, 1, 0)),
+                                    (200.0, 160.0, 23, (0, 0, 1)), (-700.0, 133.37, 30, (1, 1, 1)), (2999.0, 0.75, 9, (0, 0, 0)),
+                                    (-5000.0, 1000.0, 9, (0, 0, 0)), (200.0, 160.0, 1, (0, 0, 0)), (10.5, 2.5, 700, (0, 0, 0))]:
+            rc, Yref = O.stft_flt(x, win, W, c0, stp, 512, *flags, intended=intended)
+            assert rc == 0
+            Y = D.stft_flt(x, win, W, c0, stp, *[bool(f) for f in flags])
+            check_spec(O, Y, Yref, flags[1], flags[2])
+            D.force_generic(True)
+            try:
+                Y = D.stft_flt(x, win, W, c0, stp, *[bool(f) for f in flags])
+            finally:
+                D.force_generic(False)
+            check_spec(O, Y, Yref, flags[1], flags[2])
+    finally:
+        D.set_flt_mode(False)
+
+
+@pytest.mark.parametrize("tag", ["s", "d"])
+def test_stft_flt_intended_against_reference_fixtures(O, D, tag):
+    g = load_golden(f"ref_flt_{tag}.npz")
+    x, win = g["x"], g["win"]
+    D.set_flt_mode(True)
+    try:
+        for i, (c0, stp, W) in enumerate(g["cases"]):
+            Y = D.stft_flt(x, win, int(W), float(c0), float(stp))
+            check_spec(O, Y, g[f"case{i}.power"])
+    finally:
+        D.set_flt_mode(False)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64, np.complex64, np.complex128])
+def test_framing_is_bit_exact(O, D, dt):
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal(1500)
+    if np.dtype(dt).kind == "c":
+        x = x + 1j * rng.standard_normal(1500)
+    x = x.astype(dt)
+    for (L, stp, snip) in [(400, 160, 0), (400, 160, 1), (64, 100, 0), (1, 1, 1), (1499, 1, 0), (7, 3000, 0)]:
+        rc, ref = O.frame_univar(x, L, stp, snip)
+        assert rc == 0
+        assert np.array_equal(D.frame_univar(x, L, stp, bool(snip)), ref)
+    for (L, W, c0, stp) in [(400, 14, 0.0, 160.0), (48, 30, -10.0, 17.3), (400, 20, -700.0, 133.37), (9, 1500, 3.3, 0.999)]:
+        ct = np.float32 if np.dtype(dt).name in ("float32", "complex64") else np.float64
+        rc, ref = O.frame_univar_flt(x, L, W, ct(c0), ct(stp))
+        assert rc == 0
+        assert np.array_equal(D.frame_univar_flt(x, L, W, c0, stp), ref)
+
+
+@pytest.mark.parametrize("tag", ["s", "d"])
+def test_framing_against_reference_fixtures(D, tag):
+    g = load_golden(f"ref_misc_{tag}.npz")
+    xc = g["x"]
+    for snip in (0, 1):
+        assert np.array_equal(D.frame_univar(xc, 48, 20, bool(snip)), g[f"frames.snip{snip}"])
+    assert np.array_equal(D.frame_univar_flt(xc, 48, 30, -10.0, 17.3), g["frames_flt"])
+    a = g["aw.x"]
+    for col in (0, 1):
+        assert np.array_equal(np.ascontiguousarray(D.apply_win(a, g["aw.w0"], 0, bool(col))), g[f"aw.dim0.col{col}"])
+        assert np.array_equal(np.ascontiguousarray(D.apply_win(a, g["aw.w1"], 1, bool(col))), g[f"aw.dim1.col{col}"])
+    gc = load_golden(f"ref_chain_{tag}.npz")
+    for snip in (0, 1):
+        fr = D.frame_univar(gc["base.x"], 400, 160, bool(snip))
+        assert np.array_equal(fr, gc[f"base.snip{snip}.frames"])
+        assert np.array_equal(D.apply_win(fr, gc["base.win"], 1), gc[f"base.snip{snip}.windowed"])
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64, np.complex64, np.complex128])
+def test_apply_win(O, D, dt):
+    rng = np.random.default_rng(2)
+    cplx = np.dtype(dt).kind == "c"
+    for shape in [(6, 5), (3, 4, 5), (2, 3, 4, 5), (7,), (1, 9)]:
+        x = rng.standard_normal(shape)
+        if cplx:
+            x = x + 1j * rng.standard_normal(shape)
+        x = x.astype(dt)
+        for dim in range(len(shape)):
+            w = rng.standard_normal(shape[dim])
+            if cplx:
+                w = w + 1j * rng.standard_normal(shape[dim])
+            w = w.astype(dt)
+            for col in (False, True):
+                rc, ref = O.apply_win(x, w, dim, col)
+                assert rc == 0
+                y = D.apply_win(x, w, dim, col)
+                if cplx:        # products and sums may be fused on the device
+                    np.testing.assert_allclose(y, ref, rtol=0, atol=4 * np.finfo(dt).eps * np.max(np.abs(ref)))
+                else:
+                    assert np.array_equal(np.asarray(y), np.asarray(ref))
+                xi = np.array(x, order="F" if col else "C")
+                D.apply_win(xi, w, dim, col, inplace=True)
+                np.testing.assert_array_equal(np.asarray(xi), np.asarray(y))
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_fft_r2hc(O, D, dt):
+    rng = np.random.default_rng(6)
+    tol = 10 * TOL[np.dtype(dt)]
+    for shape, dim, nfft in [((13, 400), 1, 512), ((400, 13), 0, 512), ((3, 50, 4), 1, 64), ((2, 3, 4, 20), 3, 32),
+                             ((5, 30), 1, 45), ((5, 30), 1, 30), ((4, 7), 1, 8), ((9,), 0, 16), ((4, 1), 1, 1),
+                             ((6, 2000), 1, 4096)]:
+        x = rng.standard_normal(shape).astype(dt)
+        for col in (False, True):
+            for sc in (False, True):
+                rc, ref = O.fft_r2hc(x, dim, nfft, col, sc)
+                assert rc == 0
+                y = D.fft_r2hc(x, dim, nfft, col, sc)
+                assert y.shape == ref.shape
+                assert np.max(np.abs(np.asarray(y) - np.asarray(ref))) <= tol * np.max(np.abs(ref))
+                # imag of DC (and of Nyquist for even nfft) is exactly zero, as the reference writes it
+                ym = np.moveaxis(np.asarray(y), dim, -1)
+                assert np.all(ym[..., 0].imag == 0)
+                if nfft % 2 == 0 and nfft > 1:
+                    assert np.all(ym[..., nfft // 2].imag == 0)
+
+
+@pytest.mark.parametrize("dt", [np.complex64, np.complex128])
+def test_fft_power(O, D, dt):
+    rng = np.random.default_rng(7)
+    for n in (1, 7, 257000, 1 << 20):
+        z = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(dt)
+        rc, ref = O.fft_power(z)
+        y = D.fft_power(z)
+        np.testing.assert_allclose(y, ref, rtol=2 * np.finfo(dt).eps, atol=0)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_unfused_chain_equals_fused(O, D, dt):
+    """frame_univar | apply_win | fft.fftw.r2hc | fft_power is the unfused form of stft."""
+    x = signal(31, 16000, dt)
+    win = D.hann(400, dt)
+    for snip in (False, True):
+        fr = D.frame_univar(x, 400, 160, snip)
+        wn = D.apply_win(fr, win, 1, inplace=False)
+        z = D.fft_r2hc(wn, 1, 512)
+        p = D.fft_power(z)
+        check_spec(O, p, D.stft(x, win, 160, snip))
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_batch_host_and_device(O, D, dt):
+    import torch
+    rng = np.random.default_rng(12)
+    B, N = 5, 4000
+    big = rng.standard_normal((B, N + 37)).astype(dt)
+    x = big[:, :N]                      # row stride N+37
+    win = D.hamming(400, dt)
+    Yb = D.stft_batch(x, win, 160)
+    for b in range(B):
+        assert np.array_equal(Yb[b], D.stft(np.ascontiguousarray(x[b]), win, 160))
+    xt = torch.from_numpy(big).cuda()[:, :N]
+    wt = torch.from_numpy(win).cuda()
+    Yd = D.stft_dev(xt, wt, 160)
+    torch.cuda.synchronize()
+    assert np.array_equal(Yd.cpu().numpy(), Yb)
+    D.set_flt_mode(True)
+    try:
+        Yf = D.stft_flt_dev(xt, wt, 20, 200.0, 160.0).cpu().numpy()
+        for b in range(B):
+            assert np.array_equal(Yf[b], D.stft_flt(np.ascontiguousarray(x[b]), win, 20, 200.0, 160.0))
+    finally:
+        D.set_flt_mode(False)
+    zt = torch.view_as_complex(torch.from_numpy(rng.standard_normal((1000, 2)).astype(dt)).cuda())
+    np.testing.assert_array_equal(D.fft_power_dev(zt).cpu().numpy(), D.fft_power(zt.cpu().numpy()))
+
+
+def test_nan_stays_in_its_own_frames(O, D):
+    """A NaN sample must only reach the frames that contain it (reflection included)."""
+    x = signal(1, 8000, np.float32)
+    x[4000] = np.nan
+    win = D.hann(400, np.float32)
+    rc, Yref = O.stft(x, win, 160, 512)
+    for generic in (False, True):
+        D.force_generic(generic)
+        try:
+            Y = D.stft(x, win, 160)
+        finally:
+            D.force_generic(False)
+        assert np.array_equal(np.isnan(Y).any(axis=1), np.isnan(Yref).any(axis=1))
+        ok = ~np.isnan(Yref).any(axis=1)
+        check_spec(O, Y[ok], Yref[ok])
+
+
+def test_log_of_silence_is_minus_inf(D):
+    Y = D.stft(np.zeros(4000, np.float32), D.hann(400), 160, lg=True)
+    assert np.all(np.isneginf(Y))
+    Y = D.stft(np.zeros(4000, np.float64), D.hann(400, np.float64), 160, amp=True, lg=True)
+    assert np.all(np.isneginf(Y))
+
+
+# ---------------------------------------------------------------------------------------------------
+# full benchmark sizes: size-independent properties + sampled oracle checks
+# ---------------------------------------------------------------------------------------------------
+def test_full_size_batch_1024_utterances(O, D):
+    """1024 x 10 s @ 16 kHz float32, Hann 400 / hop 160 / nfft 512 (1 024 000 frames)."""
+    import torch
+    B, N = 1024, 160000
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    x = torch.randn((B, N), generator=g, device="cuda", dtype=torch.float32) * 0.1
+    win = torch.from_numpy(D.hann(400)).cuda()
+    Y = D.stft_dev(x, win, 160)
+    torch.cuda.synchronize()
+    assert tuple(Y.shape) == (B, 1000, 257)
+    # (1) sampled signals against the oracle (first, last, a few in between; edge frames included)
+    for b in (0, 1, 511, 1023):
+        rc, Yref = O.stft(x[b].cpu().numpy(), win.cpu().numpy(), 160, 512, exact=False)
+        check_spec(O, Y[b].cpu().numpy(), Yref)
+    # (2) shift by one hop moves interior frames by one row, bit for bit (same arithmetic, new place)
+    xs = torch.roll(x[:8], shifts=-160, dims=1)
+    Ys = D.stft_dev(xs, win, 160)
+    torch.cuda.synchronize()
+    assert torch.equal(Ys[:, 2:990], Y[:8, 3:991])
+    # (3) Parseval per frame: sum_k c_k P_k = nfft * sum_l v_l^2 (c = 1 for DC and Nyquist, else 2)
+    fr = x[:4, 40:].unfold(1, 400, 160)[:, :995] * win     # frame w of the output starts at 160 w - 120
+    e_time = (fr.double() ** 2).sum(-1) * 512
+    Pd = Y[:4, 1:996].double()
+    e_freq = 2 * Pd.sum(-1) - Pd[..., 0] - Pd[..., 256]
+    assert torch.allclose(e_freq, e_time, rtol=2e-5)
+    # (4) scaling by 2 scales power by exactly 4
+    Y2 = D.stft_dev(x[:8] * 2, win, 160)
+    torch.cuda.synchronize()
+    assert torch.equal(Y2, Y[:8] * 4)
+
+
+def test_full_size_long_flt_double(O, D):
+    """One channel of an hour-long float64 signal through stft_flt (Povey 400, hop 160.0, c0 = 200)."""
+    import torch
+    N = 57_600_000
+    g = torch.Generator(device="cuda").manual_seed(99)
+    x = torch.randn((1, N), generator=g, device="cuda", dtype=torch.float64)
+    win = torch.from_numpy(D.povey(400, np.float64)).cuda()
+    W = int((N - 1 - 200) // 160)
+    Y = D.stft_flt_dev(x, win, W, 200.0, 160.0)
+    torch.cuda.synchronize()
+    assert tuple(Y.shape) == (1, W, 257)
+    xh = x[0].cpu().numpy()
+    # head and tail against the oracle (the tail includes the zero-padded right edge)
+    rc, Yref = O.stft_flt(xh[:20000], win.cpu().numpy(), 100, 200.0, 160.0, intended=True)
+    check_spec(O, Y[0, :100].cpu().numpy(), Yref)
+    w0 = W - 50
+    s0 = w0 * 160
+    rc, Yref = O.stft_flt(xh[s0:], win.cpu().numpy(), 50, 200.0, 160.0, intended=True)
+    check_spec(O, Y[0, w0:].cpu().numpy(), Yref)
+    # middle: equals the integer-hop stft with snipped edges on the same samples
+    mid = 180000
+    Ym = D.stft_dev(x[:, mid * 160: mid * 160 + 160 * 99 + 400], win, 160, snip_edges=True)
+    torch.cuda.synchronize()
+    assert torch.equal(Ym[0], Y[0, mid: mid + 100])
+
+
+def test_full_size_long_window_4096(O, D):
+    """One channel of 1 h @ 48 kHz float32, Blackman-Harris L = nfft = 4096, hop 1024."""
+    import torch
+    N = 172_800_000
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.randn((1, N), generator=g, device="cuda", dtype=torch.float32)
+    win = torch.from_numpy(D.blackmanharris(4096)).cuda()
+    Y = D.stft_dev(x, win, 1024)
+    torch.cuda.synchronize()
+    W = (N + 512) // 1024
+    assert tuple(Y.shape) == (1, W, 2049)
+    xh = x[0, :1024 * 40].cpu().numpy()
+    rc, Yref = O.stft(xh, win.cpu().numpy(), 1024, 4096, exact=False)
+    check_spec(O, Y[0, :30].cpu().numpy(), Yref[:30])
+    Y2 = D.stft_dev(x * 2, win, 1024)
+    torch.cuda.synchronize()
+    assert torch.equal(Y2, Y * 4)

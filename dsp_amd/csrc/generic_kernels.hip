@@ -97,6 +97,7 @@ hipError_t launch_stft_pow2(T *Y, const T *X, const T *win, const T *tw, const F
 {
     const size_t lds = (size_t)d.nfft * sizeof(T) + 64;
     static size_t granted = 0;
+    (void)hipGetLastError();
     if (lds > 48 * 1024 && lds > granted) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&stft_pow2_kernel<T>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -172,6 +173,7 @@ hipError_t launch_stft_direct(T *Y, const T *X, const T *win, const T *tw, const
 {
     const size_t lds = (size_t)d.L * sizeof(T) + 64;
     static size_t granted = 0;
+    (void)hipGetLastError();
     if (lds > 48 * 1024 && lds > granted) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&stft_direct_kernel<T>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -362,6 +364,7 @@ hipError_t launch_r2hc(T *Y, const T *X, const T *tw, size_t V, size_t K, size_t
     if (V == 0) { return hipSuccess; }
     const size_t lds = (pow2 ? nfft : Lx) * sizeof(T) + 64;
     static size_t granted = 0;
+    (void)hipGetLastError();
     if (lds > 48 * 1024 && lds > granted) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&r2hc_kernel<T>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void stft_r512_kernel(T *__restrict__ Y, const
     }
 }
 
-constexpr int R512_XS_CAP = 4096;   // staged samples per wave at most
+constexpr int R512_XS_CAP = 2048;   // staged samples per wave at most (4 whole frames; keeps LDS under 160 KB for double)
 
 template <typename T>
 bool r512_supported(const FrameDesc &d)
@@ -255,6 +255,7 @@ hipError_t launch_stft_r512(T *Y, const T *X, const T *win, const T *tw, const F
     xs_len = (xs_len + 3) & ~3;                       // keeps the exchange region 16-byte aligned
     const size_t lds = ((WINREG ? 0 : 512) + 4 * ((size_t)xs_len + 4 * R512_EXF * 2)) * sizeof(T);
     static size_t granted = 0;
+    (void)hipGetLastError();
     if (lds > 48 * 1024 && lds > granted) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&stft_r512_kernel<T, WINREG>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

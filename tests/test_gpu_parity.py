@@ -4,8 +4,10 @@ oracle on the same seeded inputs, and against the fixtures made from executed re
 Tolerance of the path (stated once, used everywhere): per-frame-normalised max error
     max_f |Y - Yref| / max_f |Yref|  <=  1e-5 (float32), 1e-12 (float64)
 for power and amplitude outputs.  Log outputs are compared after exp() with the same bound (an
-element-wise bound in the log domain is meaningless on bins that are 1e-12 of the frame maximum)
-and must have -inf exactly where the oracle has it.  Copies (framing) are bit-exact.
+element-wise bound in the log domain is meaningless on bins that are 1e-12 of the frame maximum, and
+a bin that is pure rounding residue, such as DC after mean removal, may be exactly 0 -> -inf in one
+implementation and 1e-12 of the maximum in the other); log of an all-zero frame must be -inf
+(test_log_of_silence_is_minus_inf).  Copies (framing) are bit-exact.
 """
 import numpy as np
 import pytest
@@ -25,7 +27,7 @@ def check_spec(O, Y, Yref, amp=False, lg=False, tol=None):
     assert Y.shape == Yref.shape and Y.dtype == Yref.dtype
     tol = TOL[Y.dtype] if tol is None else tol
     if lg:
-        assert np.array_equal(np.isneginf(Y), np.isneginf(Yref))
+        assert not np.any(np.isposinf(Y)) and not np.any(np.isposinf(Yref))
         with np.errstate(over="ignore"):
             Y = np.exp(Y.astype(np.float64))
             Yref = np.exp(Yref.astype(np.float64))

@@ -1,0 +1,61 @@
+// Register-resident 16-point FFT building blocks shared by the 512-point kernels.
+#pragma once
+#include "stft_common.h"
+
+namespace dsp {
+
+// forward 4-point DFT in place, natural order.  Z3: input 3 is known to be zero.
+template <typename T, bool Z3 = false>
+__device__ __forceinline__ void dft4(T &r0, T &i0, T &r1, T &i1, T &r2, T &i2, T &r3, T &i3)
+{
+    const T ar = r0 + r2, ai = i0 + i2, br = r0 - r2, bi = i0 - i2;
+    const T cr = Z3 ? r1 : r1 + r3, ci = Z3 ? i1 : i1 + i3, dr = Z3 ? r1 : r1 - r3, di = Z3 ? i1 : i1 - i3;
+    r0 = ar + cr; i0 = ai + ci;
+    r2 = ar - cr; i2 = ai - ci;
+    r1 = br + di; i1 = bi - dr;      // b - i d
+    r3 = br - di; i3 = bi + dr;      // b + i d
+}
+
+// (r + i im) *= (c + i s)
+template <typename T>
+__device__ __forceinline__ void cmul(T &r, T &i, const T c, const T s)
+{
+    const T t = r * c - i * s;
+    i = r * s + i * c;
+    r = t;
+}
+
+// Forward 16-point DFT of (re[n], im[n]), n = 4 n1 + n2, as 4 x 4.  On return X[k] sits in slot
+// 4 (k & 3) + (k >> 2).  Inputs n >= NZ are known to be zero (NZ in 13..16).
+template <typename T, int NZ = 16>
+__device__ __forceinline__ void dft16(T (&re)[16], T (&im)[16])
+{
+    static_assert(NZ >= 13 && NZ <= 16, "only the last row of each column may be known-zero");
+    constexpr T C1 = T(0.92387953251128675612818318939678829L);   // cos(pi/8)
+    constexpr T S1 = T(0.38268343236508977172845998403039887L);   // sin(pi/8)
+    constexpr T R2 = T(0.70710678118654752440084436210484904L);   // sqrt(1/2)
+    dft4<T, (NZ <= 12)>(re[0], im[0], re[4], im[4], re[8], im[8], re[12], im[12]);
+    dft4<T, (NZ <= 13)>(re[1], im[1], re[5], im[5], re[9], im[9], re[13], im[13]);
+    dft4<T, (NZ <= 14)>(re[2], im[2], re[6], im[6], re[10], im[10], re[14], im[14]);
+    dft4<T, (NZ <= 15)>(re[3], im[3], re[7], im[7], re[11], im[11], re[15], im[15]);
+    // slot 4 k1 + n2 now holds a[n2][k1]; multiply by W16^(n2 k1) = (cos, -sin)(pi n2 k1 / 8)
+    cmul(re[5], im[5], C1, -S1);     // 1
+    cmul(re[6], im[6], R2, -R2);     // 2
+    cmul(re[7], im[7], S1, -C1);     // 3
+    cmul(re[9], im[9], R2, -R2);     // 2
+    { const T t = re[10]; re[10] = im[10]; im[10] = -t; }   // 4: times -i
+    cmul(re[11], im[11], -R2, -R2);  // 6
+    cmul(re[13], im[13], S1, -C1);   // 3
+    cmul(re[14], im[14], -R2, -R2);  // 6
+    cmul(re[15], im[15], -C1, S1);   // 9
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) {
+        dft4(re[4 * k1], im[4 * k1], re[4 * k1 + 1], im[4 * k1 + 1], re[4 * k1 + 2], im[4 * k1 + 2],
+             re[4 * k1 + 3], im[4 * k1 + 3]);
+    }
+}
+__host__ __device__ constexpr int slot16(int k) { return 4 * (k & 3) + (k >> 2); }
+
+constexpr int R512_EXF = 16 * 17;   // complex slots per frame in the exchange region (row pitch 17)
+
+}  // namespace dsp

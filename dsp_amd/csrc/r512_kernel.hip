@@ -8,64 +8,10 @@
 // the power step.  Each wave walks a run of consecutive frames of one signal, stages the span of its
 // 4 frames in LDS once per step and stores spectrogram rows as whole 256-byte wave stores.
 #include "stft_common.h"
+#include "fft16.h"
 
 namespace dsp {
 
-// =================================================================================================
-// register-resident 512-point family
-// =================================================================================================
-// forward 4-point DFT in place, natural order
-template <typename T>
-__device__ __forceinline__ void dft4(T &r0, T &i0, T &r1, T &i1, T &r2, T &i2, T &r3, T &i3)
-{
-    const T ar = r0 + r2, ai = i0 + i2, br = r0 - r2, bi = i0 - i2;
-    const T cr = r1 + r3, ci = i1 + i3, dr = r1 - r3, di = i1 - i3;
-    r0 = ar + cr; i0 = ai + ci;
-    r2 = ar - cr; i2 = ai - ci;
-    r1 = br + di; i1 = bi - dr;      // b - i d
-    r3 = br - di; i3 = bi + dr;      // b + i d
-}
-
-// (r + i im) *= (c + i s)
-template <typename T>
-__device__ __forceinline__ void cmul(T &r, T &i, const T c, const T s)
-{
-    const T t = r * c - i * s;
-    i = r * s + i * c;
-    r = t;
-}
-
-// Forward 16-point DFT of (re[n], im[n]), n = 4 n1 + n2, as 4 x 4.  On return X[k] sits in slot
-// 4 (k & 3) + (k >> 2).
-template <typename T>
-__device__ __forceinline__ void dft16(T (&re)[16], T (&im)[16])
-{
-    constexpr T C1 = T(0.92387953251128675612818318939678829L);   // cos(pi/8)
-    constexpr T S1 = T(0.38268343236508977172845998403039887L);   // sin(pi/8)
-    constexpr T R2 = T(0.70710678118654752440084436210484904L);   // sqrt(1/2)
-#pragma unroll
-    for (int n2 = 0; n2 < 4; ++n2) {
-        dft4(re[n2], im[n2], re[4 + n2], im[4 + n2], re[8 + n2], im[8 + n2], re[12 + n2], im[12 + n2]);
-    }
-    // slot 4 k1 + n2 now holds a[n2][k1]; multiply by W16^(n2 k1) = (cos, -sin)(pi n2 k1 / 8)
-    cmul(re[5], im[5], C1, -S1);     // 1
-    cmul(re[6], im[6], R2, -R2);     // 2
-    cmul(re[7], im[7], S1, -C1);     // 3
-    cmul(re[9], im[9], R2, -R2);     // 2
-    { const T t = re[10]; re[10] = im[10]; im[10] = -t; }   // 4: times -i
-    cmul(re[11], im[11], -R2, -R2);  // 6
-    cmul(re[13], im[13], S1, -C1);   // 3
-    cmul(re[14], im[14], -R2, -R2);  // 6
-    cmul(re[15], im[15], -C1, S1);   // 9
-#pragma unroll
-    for (int k1 = 0; k1 < 4; ++k1) {
-        dft4(re[4 * k1], im[4 * k1], re[4 * k1 + 1], im[4 * k1 + 1], re[4 * k1 + 2], im[4 * k1 + 2],
-             re[4 * k1 + 3], im[4 * k1 + 3]);
-    }
-}
-__host__ __device__ constexpr int slot16(int k) { return 4 * (k & 3) + (k >> 2); }
-
-constexpr int R512_EXF = 16 * 17;   // complex slots per frame in the exchange region (row pitch 17)
 
 template <typename T, bool WINREG>
 __global__ __launch_bounds__(256) void stft_r512_kernel(T *__restrict__ Y, const T *__restrict__ X,
@@ -249,6 +195,7 @@ bool r512_supported(const FrameDesc &d)
 template <typename T>
 hipError_t launch_stft_r512(T *Y, const T *X, const T *win, const T *tw, const FrameDesc &d, hipStream_t s)
 {
+    if (r512_fast_supported(d)) { return launch_stft_r512_fast<T>(Y, X, win, tw, d, s); }
     constexpr bool WINREG = (sizeof(T) == 4);
     const bool span = (d.tbl == nullptr) && (3ll * d.stp + 512 <= R512_XS_CAP);
     int xs_len = span ? 3 * d.stp + 512 : 2048;

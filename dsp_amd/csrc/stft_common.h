@@ -70,6 +70,8 @@ template <typename T> hipError_t launch_stft_pow2(T *Y, const T *X, const T *win
 template <typename T> hipError_t launch_stft_direct(T *Y, const T *X, const T *win, const T *tw, const FrameDesc &d, hipStream_t s);
 template <typename T> hipError_t launch_stft_r512(T *Y, const T *X, const T *win, const T *tw, const FrameDesc &d, hipStream_t s);
 template <typename T> bool r512_supported(const FrameDesc &d);
+bool r512_fast_supported(const FrameDesc &d);
+template <typename T> hipError_t launch_stft_r512_fast(T *Y, const T *X, const T *win, const T *tw, const FrameDesc &d, hipStream_t s);
 
 // ---- unfused kernels (unfused_kernels.hip) ----------------------------------------------------
 template <typename T> hipError_t launch_fft_power(T *Y, const T *X, size_t N, hipStream_t s);

@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdsp_stft_hip.so")
+# DSP_AMD_LIB selects another build of the same library (kernel A/B runs)
+LIB_PATH = os.environ.get("DSP_AMD_LIB") or os.path.join(_HERE, "libdsp_stft_hip.so")
 
 _sz, _int, _vp = C.c_size_t, C.c_int, C.c_void_p
 _f, _d = C.c_float, C.c_double

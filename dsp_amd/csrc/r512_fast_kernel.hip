@@ -11,6 +11,7 @@
 //     removes the per-element selects and branches of the general kernel.
 #include "stft_common.h"
 #include "fft16.h"
+#include <cstdlib>
 
 namespace dsp {
 
@@ -24,25 +25,79 @@ struct R512FastArgs {
     int rd_shift;         // edge == 1: samples are read at n - rd_shift
     int edge;             // 0 reflect, 1 zero
     int amp, lg;
-    int chunk, nchunk;    // frames per run, runs per signal
-    int total_chunks;     // B * nchunk
+    int sps;              // steps (groups of 4 consecutive frames) per signal
+    int steps;            // B * sps
 };
 
 constexpr int R512F_WAVE_ELEMS = 4 * R512_EXF * 2;   // T elements of LDS per wave (>= 1024 staged samples)
+
+// value of lane (16 - i) % 16 of the same 16-lane row (row_mirror, then row_ror:1)
+__device__ __forceinline__ int dpp_partner16_i(int v)
+{
+    const int m = __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);
+    return __builtin_amdgcn_update_dpp(0, m, 0x121, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float dpp_partner16(float v) { return __int_as_float(dpp_partner16_i(__float_as_int(v))); }
+__device__ __forceinline__ double dpp_partner16(double v)
+{
+    const int lo = dpp_partner16_i(__double2loint(v)), hi = dpp_partner16_i(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
 
 template <typename T> struct vec16;                   // 16-byte vector of T
 template <> struct vec16<float> { using type = float4; static constexpr int n = 4; };
 template <> struct vec16<double> { using type = double2; static constexpr int n = 2; };
 
+#ifndef R512F_TW_LDS
+#define R512F_TW_LDS 0          // 1: pass-1 twiddles come from an LDS table instead of 30 registers
+#endif
+#ifndef R512F_WIN_LDS
+#define R512F_WIN_LDS 0         // 1: float window taps come from LDS too (double always does)
+#endif
+#ifndef R512F_ABLATE
+#define R512F_ABLATE 0          // diagnostic builds: 1 = memory traffic only, 2 = no stores, 3 = no LDS output stage
+#endif
+#ifndef R512F_NT_STORE
+#define R512F_NT_STORE 0        // 1: spectrogram rows are stored with the non-temporal hint
+#endif
+#ifndef R512F_NT_LOAD
+#define R512F_NT_LOAD 0         // 1: signal spans are loaded with the non-temporal hint
+#endif
+#if R512F_NT_STORE
+#define R512F_ST(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define R512F_ST(ptr, val) (*(ptr) = (val))
+#endif
+#ifndef R512F_STAMPS
+#define R512F_STAMPS 0          // diagnostic builds: 1 = per-phase s_memtime sums into g_r512f_stamps
+#endif
+#if R512F_STAMPS
+__device__ unsigned long long g_r512f_stamps[8192 * 8];
+#define R512F_STAMP(i)                                                                            \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        unsigned long long t_;                                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");             \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        st_acc[i] += t_ - st_last; st_last = t_;                                                  \
+    } while (0)
+#else
+#define R512F_STAMP(i) do {} while (0)
+#endif
+#ifndef R512F_MINWAVES_F32
+#define R512F_MINWAVES_F32 2
+#endif
+
 template <typename T, int NR, bool MN0, bool EPI>
-__global__ __launch_bounds__(256) void stft_r512_fast_kernel(T *__restrict__ Y, const T *__restrict__ X,
+__global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) void stft_r512_fast_kernel(T *__restrict__ Y, const T *__restrict__ X,
                                                               const T *__restrict__ win, const T *__restrict__ tw,
                                                               const R512FastArgs a)
 {
     using T2 = typename vec2<T>::type;
     using TV = typename vec16<T>::type;
     constexpr int VEC = vec16<T>::n, NV = 16 / VEC;        // 16 staged elements per lane
-    constexpr bool WINREG = (sizeof(T) == 4);
+    constexpr bool WINREG = (sizeof(T) == 4) && !R512F_WIN_LDS;
+    constexpr bool TWREG = !R512F_TW_LDS;
     constexpr int M = 256, F = 257;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -52,19 +107,30 @@ __global__ __launch_bounds__(256) void stft_r512_fast_kernel(T *__restrict__ Y, 
 
     T *xs = reinterpret_cast<T *>(smem_raw) + wv * R512F_WAVE_ELEMS;   // staged span; aliases the exchange tile
     T2 *ex = reinterpret_cast<T2 *>(xs);
-    T *wtab = reinterpret_cast<T *>(smem_raw) + 4 * R512F_WAVE_ELEMS;  // halved window (double only)
+    T *wtab = reinterpret_cast<T *>(smem_raw) + 4 * R512F_WAVE_ELEMS;  // halved window, 512 T
+    T2 *ttab = reinterpret_cast<T2 *>(wtab + 512);                     // W256^(j k1) at [k1][j], 256 T2
 
     // ---- per-lane constants ----
     T twr[16], twi[16];                                    // W256^(j k1) = W512^(2 j k1)
+    if (TWREG) {
 #pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1) {
-        int idx = 2 * j * k1;
+        for (int k1 = 1; k1 < 16; ++k1) {
+            int idx = 2 * j * k1;
+            T sg = T(1);
+            if (idx >= 256) { idx -= 256; sg = T(-1); }
+            twr[k1] = sg * tw[2 * idx]; twi[k1] = sg * tw[2 * idx + 1];
+        }
+    } else {
+        const int k1 = tid >> 4, jj = tid & 15;
+        int idx = 2 * jj * k1;
         T sg = T(1);
         if (idx >= 256) { idx -= 256; sg = T(-1); }
-        twr[k1] = sg * tw[2 * idx]; twi[k1] = sg * tw[2 * idx + 1];
+        T2 t; t.x = sg * tw[2 * idx]; t.y = sg * tw[2 * idx + 1];
+        ttab[tid] = t;
     }
-    const T ow0r = tw[2 * lane], ow0i = tw[2 * lane + 1];
-    const T ow1r = tw[2 * (lane + 64)], ow1i = tw[2 * (lane + 64) + 1];
+    T owr[8], owi[8];                                      // W512^(j + 16 k2), k2 < 8
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) { owr[k2] = tw[2 * (j + 16 * k2)]; owi[k2] = tw[2 * (j + 16 * k2) + 1]; }
     T hw0[NR], hw1[NR];                                    // halved window taps of this lane's columns
     if (WINREG) {
 #pragma unroll
@@ -75,10 +141,8 @@ __global__ __launch_bounds__(256) void stft_r512_fast_kernel(T *__restrict__ Y, 
         }
     } else {
         for (int l = tid; l < 512; l += 256) { wtab[l] = (l < L) ? T(0.5) * win[l] : T(0); }
-        __syncthreads();
     }
-    const int zm0 = (M - lane) & (M - 1);                  // partner bins of lane and lane + 64
-    const int zm1 = M - 64 - lane;
+    if (!WINREG || !TWREG) { __syncthreads(); }
     const int need = 3 * a.stp + 512;
     const T *xrow = xs + f * a.stp + 2 * j;
 
@@ -90,7 +154,13 @@ __global__ __launch_bounds__(256) void stft_r512_fast_kernel(T *__restrict__ Y, 
         const bool inside = s0 >= 0 && s0 + 1024 <= a.N && (a.edge == 0 || s0 >= a.rd_shift);
         if (inside && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
 #pragma unroll
-            for (int q = 0; q < NV; ++q) { pre[q] = reinterpret_cast<const TV *>(src)[q * 64 + lane]; }
+            for (int q = 0; q < NV; ++q) {
+#if R512F_NT_LOAD
+                pre[q] = __builtin_nontemporal_load(reinterpret_cast<const TV *>(src) + (q * 64 + lane));
+#else
+                pre[q] = reinterpret_cast<const TV *>(src)[q * 64 + lane];
+#endif
+            }
         } else {
             FrameDesc d{};
             d.N = a.N; d.edge = a.edge;
@@ -108,40 +178,57 @@ __global__ __launch_bounds__(256) void stft_r512_fast_kernel(T *__restrict__ Y, 
         }
     };
 
-    int cid = blockIdx.x * 4 + wv;
-    if (cid >= a.total_chunks) { return; }
-    const int cstride = gridDim.x * 4;
-    int b = cid / a.nchunk;
-    int w = (cid - b * a.nchunk) * a.chunk;
-    int wend = min(w + a.chunk, a.W);
+    // Work distribution: the steps of the whole batch are cut into 8 contiguous ranges, one per group
+    // of workgroups that share an XCD (blockIdx % 8), and inside a range the waves take steps
+    // round-robin.  The waves of a range therefore read and write one moving window of adjacent
+    // addresses (good DRAM page locality, and the samples two neighbouring steps share come from the
+    // same L2) instead of thousands of separate streams.
+    const int xcd = blockIdx.x & 7, nwg_x = gridDim.x >> 3;
+    const int s_lo = (int)((long long)a.steps * xcd / 8), s_hi = (int)((long long)a.steps * (xcd + 1) / 8);
+    const int sstride = nwg_x * 4;
+    int sid = s_lo + (blockIdx.x >> 3) * 4 + wv;
+    if (sid >= s_hi) { return; }
+    int b = sid / a.sps;
+    int w = (sid - b * a.sps) * 4;
     const T *xb = X + (long long)b * a.ldx;
     T *yb = Y + (long long)b * a.W * F;
-    load_span(xb, w);
 
-    while (true) {
-        // ---- commit the fetched span to LDS, then start fetching the next one ----
-#pragma unroll
-        for (int q = 0; q < NV; ++q) { reinterpret_cast<TV *>(xs)[q * 64 + lane] = pre[q]; }
-        wave_sync();
-        int nw = w + 4, nwend = wend, ncid = cid;
-        const T *nxb = xb;
-        T *nyb = yb;
-        bool more = true;
-        if (nw >= wend) {
-            ncid = cid + cstride;
-            more = ncid < a.total_chunks;
-            if (more) {
-                const int nb = ncid / a.nchunk;
-                nw = (ncid - nb * a.nchunk) * a.chunk;
-                nwend = min(nw + a.chunk, a.W);
-                nxb = X + (long long)nb * a.ldx;
-                nyb = Y + (long long)nb * a.W * F;
-            }
+    // position of the wave's next step
+    int nsid, nw;
+    const T *nxb;
+    T *nyb;
+    bool more;
+    auto advance = [&]() {
+        nsid = sid + sstride;
+        more = nsid < s_hi;
+        if (more) {
+            const int nb = nsid / a.sps;
+            nw = (nsid - nb * a.sps) * 4;
+            nxb = X + (long long)nb * a.ldx;
+            nyb = Y + (long long)nb * a.W * F;
         }
-        if (more) { load_span(nxb, nw); }
+    };
 
+#if R512F_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory");
+#endif
+    // prologue: first span to LDS, second span in flight
+    load_span(xb, w);
+#pragma unroll
+    for (int q = 0; q < NV; ++q) { reinterpret_cast<TV *>(xs)[q * 64 + lane] = pre[q]; }
+    wave_sync();
+    advance();
+    if (more) { load_span(nxb, nw); }
+
+    // Steady state per step: transform the staged span and store its rows while the next span is in
+    // flight; then commit that span to LDS and issue the fetch of the one after.  The stores of a
+    // step are unconditional and fixed in number, so the wait for the in-flight span leaves them
+    // outstanding instead of draining the store queue.
+    while (true) {
         // ---- pass 1: lane (frame f, column n2 = j): 16-point FFT over the rows n1 ----
         T re[16], im[16];
+#if R512F_ABLATE != 1
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
             if (n1 < NR) {
@@ -174,19 +261,27 @@ __global__ __launch_bounds__(256) void stft_r512_fast_kernel(T *__restrict__ Y, 
                 im[n1] -= (l + 1 < L) ? mean : T(0);
             }
         }
+#if R512F_ABLATE != 3
         dft16<T, NR>(re, im);
+#endif
+        R512F_STAMP(0);
         wave_sync();                                       // all lanes have read the span: the tile may overwrite it
+#if R512F_ABLATE != 4
         {
             T2 *exf = ex + f * R512_EXF + j;
 #pragma unroll
             for (int k1 = 0; k1 < 16; ++k1) {
                 T r = re[slot16(k1)], i = im[slot16(k1)];
-                if (k1 > 0) { cmul(r, i, twr[k1], twi[k1]); }
+                if (k1 > 0) {
+                    if (TWREG) { cmul(r, i, twr[k1], twi[k1]); }
+                    else { const T2 t = ttab[k1 * 16 + j]; cmul(r, i, t.x, t.y); }
+                }
                 T2 o; o.x = r; o.y = i;
                 exf[k1 * 17] = o;
             }
         }
         wave_sync();
+        R512F_STAMP(1);
 
         // ---- pass 2: lane (frame f, output residue k1 = j): 16-point FFT over n2 ----
         {
@@ -194,64 +289,127 @@ __global__ __launch_bounds__(256) void stft_r512_fast_kernel(T *__restrict__ Y, 
 #pragma unroll
             for (int n2 = 0; n2 < 16; ++n2) { const T2 t = exf[n2]; re[n2] = t.x; im[n2] = t.y; }
         }
+#else
+#pragma unroll
+        for (int k1 = 1; k1 < 16; ++k1) { cmul(re[k1], im[k1], twr[k1], twi[k1]); }
+#endif
+#if R512F_ABLATE != 3
         dft16<T, 16>(re, im);
-        wave_sync();
-        {
-            T2 *zf = ex + f * R512_EXF + j;
-#pragma unroll
-            for (int k2 = 0; k2 < 16; ++k2) {
-                T2 o; o.x = re[slot16(k2)]; o.y = im[slot16(k2)];
-                zf[16 * k2] = o;                           // Z[k1 + 16 k2]
-            }
-        }
-        wave_sync();
+#endif
+        R512F_STAMP(2);
 
-        // ---- real-FFT split fused with power; lane handles bins k and 256 - k of every frame ----
+        // ---- real-FFT split fused with power, in registers.  The lane holds Z[j + 16 k2] (halved);
+        // its partner Z[256 - k] for k = j + 16 k2, k2 < 8, is register 15 - k2 of lane (16 - j) % 16
+        // (register (16 - k2) % 16 of lane 0 itself when j == 0): one row_mirror + row_ror:1 DPP move.
+        // With A = Z_k + conj Z_{256-k}, B = Z_k - conj Z_{256-k}, T = -i W512^k B:
+        // |X_k|^2 = |A + T|^2 and |X_{256-k}|^2 = |A - T|^2.
+        T pw[16];                                          // pw[k2] = P[k], pw[8 + k2] = P[256 - k]
+        T p128 = T(4) * (re[slot16(8)] * re[slot16(8)] + im[slot16(8)] * im[slot16(8)]);   // lane j == 0 only
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (w + g < wend) {
-                const T2 *zf = ex + g * R512_EXF;
-                T *y = yb + (unsigned)((w + g) * F);
+        for (int k2 = 0; k2 < 8; ++k2) {
+            const T zx = re[slot16(k2)], zy = im[slot16(k2)];
+            // (the empty asm keeps the compiler from turning the select of two array elements into a
+            // select of the index, which it would lower to a 16-way chain of conditional moves)
+            T x0 = re[slot16((16 - k2) & 15)], x1 = re[slot16(15 - k2)];
+            T y0 = im[slot16((16 - k2) & 15)], y1 = im[slot16(15 - k2)];
+            asm volatile("" : "+v"(x0), "+v"(x1), "+v"(y0), "+v"(y1));
+            const T sx = (j == 0) ? x0 : x1;
+            const T sy = (j == 0) ? y0 : y1;
+            const T mx = dpp_partner16(sx), my = dpp_partner16(sy);
+            const T ar = zx + mx, ai = zy - my, br = zx - mx, bi = zy + my;
+            const T wr = owr[k2], wi = owi[k2];
+            const T tr = br * wi + bi * wr, ti = bi * wi - br * wr;
+            const T pr = ar + tr, pi = ai + ti, qr = ar - tr, qi = ai - ti;
+            pw[k2] = pr * pr + pi * pi;
+            pw[8 + k2] = qr * qr + qi * qi;
+        }
+        if (EPI) {
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const int k = lane + 64 * m;
-                    const T2 z = zf[k], zm = zf[m ? zm1 : zm0];
-                    const T wr = m ? ow1r : ow0r, wi = m ? ow1i : ow0i;
-                    const T ar = z.x + zm.x, ai = z.y - zm.y, br = z.x - zm.x, bi = z.y + zm.y;
-                    const T tr = br * wi + bi * wr, ti = bi * wi - br * wr;
-                    const T pr = ar + tr, pi = ai + ti, qr = ar - tr, qi = ai - ti;
-                    T p = pr * pr + pi * pi, q = qr * qr + qi * qi;
-                    if (EPI) { p = power_epilogue(p, a.amp, a.lg); q = power_epilogue(q, a.amp, a.lg); }
-                    y[k] = p;
-                    y[M - k] = q;
+            for (int i = 0; i < 16; ++i) { pw[i] = power_epilogue(pw[i], a.amp, a.lg); }
+            p128 = power_epilogue(p128, a.amp, a.lg);
+        }
+        wave_sync();                                       // every lane has read its tile row: reuse the region
+        {
+            T *pf = xs + f * F + j;                        // 4 rows of 257 values, as they lie in Y
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) {
+                pf[16 * k2] = pw[k2];                      // bin j + 16 k2
+                pf[M - 2 * j - 16 * k2] = pw[8 + k2];      // bin 256 - (j + 16 k2)
+            }
+            if (j == 0) { pf[128] = p128; }
+        }
+        wave_sync();
+        R512F_STAMP(3);
+#endif
+
+        // ---- store the rows of the step: 1028 consecutive values of Y (fewer at the end of a signal:
+        // the index is clamped, so the surplus lanes rewrite the last value with itself and the number
+        // of store instructions per step stays fixed)
+        {
+            T *yblk = yb + (unsigned)(w * F);
+            if (a.W - w >= 4) {
+#pragma unroll
+                for (int i = 0; i < 17; ++i) {
+                    // the 17th instruction carries the last 4 values; its other lanes repeat value 1027
+                    const int idx = (i < 16) ? lane + 64 * i : 1024 + (lane & 3);
+#if R512F_ABLATE == 2
+                    const T v = xs[idx];
+                    if (a.N == -12345) { yblk[idx] = v; }
+                    asm volatile("" :: "v"(v));
+#else
+                    R512F_ST(yblk + idx, xs[idx]);
+#endif
                 }
-                if (lane == 0) {
-                    const T2 z = zf[128];                  // bin 128 pairs with itself (Z holds half values)
-                    T p = T(4) * (z.x * z.x + z.y * z.y);
-                    if (EPI) { p = power_epilogue(p, a.amp, a.lg); }
-                    y[128] = p;
+            } else {
+                const int last = (a.W - w) * F - 1;
+#pragma unroll
+                for (int i = 0; i < 17; ++i) {
+                    const int idx = min(lane + 64 * i, last);
+                    R512F_ST(yblk + idx, xs[idx]);
                 }
             }
         }
+        R512F_STAMP(4);
         if (!more) { break; }
         wave_sync();                                       // tile reads are done before the next span lands
-        cid = ncid; w = nw; wend = nwend; xb = nxb; yb = nyb;
+
+        // ---- commit the span that was in flight, step forward, start the next fetch ----
+#pragma unroll
+        for (int q = 0; q < NV; ++q) { reinterpret_cast<TV *>(xs)[q * 64 + lane] = pre[q]; }
+        wave_sync();
+        R512F_STAMP(5);
+        sid = nsid; w = nw; xb = nxb; yb = nyb;
+        advance();
+        if (more) { load_span(nxb, nw); }
+        R512F_STAMP(6);
     }
+#if R512F_STAMPS
+    if (lane == 0) {
+        const int gw = blockIdx.x * 4 + wv;
+        if (gw < 8192) { for (int i = 0; i < 8; ++i) { g_r512f_stamps[gw * 8 + i] = st_acc[i]; } }
+    }
+#endif
 }
+#if R512F_STAMPS
+extern "C" int dsp_debug_read_stamps(unsigned long long *dst, size_t n)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_r512f_stamps), n * sizeof(unsigned long long));
+}
+#endif
 
 // Conditions of the fast path: frames at ss0 + w*hop, hop even with 3*hop + 512 <= 1024, and every
 // index of one signal's input and output fits 31 bits.
 bool r512_fast_supported(const FrameDesc &d)
 {
     return d.tbl == nullptr && d.nfft == 512 && d.L >= 1 && d.L <= 512 && !(d.stp & 1) && 3ll * d.stp + 512 <= 1024 &&
-           d.N < (1ll << 31) - 4096 && (long long)d.W * 257 < (1ll << 30) && d.ss0 > -(1ll << 30) && d.ss0 < (1ll << 30) &&
+           d.N < (1ll << 31) - 4096 && (long long)d.W * 257 < (1ll << 30) && (long long)d.B * ((d.W + 3) / 4) < (1ll << 30) && d.ss0 > -(1ll << 30) && d.ss0 < (1ll << 30) &&
            d.rd_shift >= 0 && d.rd_shift < (1ll << 30);
 }
 
 template <typename T, int NR, bool MN0, bool EPI>
 static hipError_t launch_fast_inst(T *Y, const T *X, const T *win, const T *tw, const R512FastArgs &a, hipStream_t s)
 {
-    const size_t lds = (4 * (size_t)R512F_WAVE_ELEMS + (sizeof(T) == 4 ? 0 : 512)) * sizeof(T);
+    const size_t lds = (4 * (size_t)R512F_WAVE_ELEMS + 512 + 512) * sizeof(T);
     static size_t granted = 0;
     (void)hipGetLastError();
     if (lds > 48 * 1024 && lds > granted) {
@@ -260,8 +418,10 @@ static hipError_t launch_fast_inst(T *Y, const T *X, const T *win, const T *tw, 
         if (e != hipSuccess) { return e; }
         granted = lds;
     }
-    long long grid = ((long long)a.total_chunks + 3) / 4;
-    if (grid > 256 * 4) { grid = 256 * 4; }
+    static const int wgs_per_cu = [] { const char *e = getenv("DSP_R512F_WGS_PER_CU"); return e ? atoi(e) : 4; }();
+    long long grid = ((long long)a.steps + 3) / 4;
+    if (grid > 256ll * wgs_per_cu) { grid = 256ll * wgs_per_cu; }
+    grid = (grid + 7) & ~7ll;                           // whole groups of 8 workgroups (one per XCD)
     hipLaunchKernelGGL((stft_r512_fast_kernel<T, NR, MN0, EPI>), dim3((unsigned)grid), dim3(256), lds, s, Y, X, win, tw, a);
     return hipGetLastError();
 }
@@ -272,15 +432,8 @@ hipError_t launch_stft_r512_fast(T *Y, const T *X, const T *win, const T *tw, co
     R512FastArgs a{};
     a.ldx = d.ldx; a.N = (int)d.N; a.L = d.L; a.W = d.W; a.stp = d.stp; a.ss0 = (int)d.ss0;
     a.rd_shift = (int)d.rd_shift; a.edge = d.edge; a.amp = d.amp; a.lg = d.lg;
-    // runs of consecutive frames per wave: long enough to amortise the per-wave constants and the
-    // first (unhidden) fetch, short enough that every wave slot of the chip gets several runs
-    const long long frames = (long long)d.B * d.W;
-    long long chunk = frames / (256ll * 16 * 8);
-    chunk = chunk < 8 ? 8 : (chunk > 64 ? 64 : chunk);
-    chunk &= ~3ll;
-    a.chunk = (int)chunk;
-    a.nchunk = (int)((d.W + chunk - 1) / chunk);
-    a.total_chunks = d.B * a.nchunk;
+    a.sps = (d.W + 3) / 4;
+    a.steps = d.B * a.sps;
     const bool epi = d.amp || d.lg;
     const bool nr13 = d.L > 384 && d.L <= 416;
 #define DSP_R512F(NR_, MN0_, EPI_) launch_fast_inst<T, NR_, MN0_, EPI_>(Y, X, win, tw, a, s)

@@ -144,6 +144,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
     }
     if (!WINREG || !TWREG) { __syncthreads(); }
     const int need = 3 * a.stp + 512;
+    const int nvec = (3 * a.stp + 32 * NR + VEC - 1) / VEC;   // 16-byte vectors of a span that pass 1 reads
     const T *xrow = xs + f * a.stp + 2 * j;
 
     // ---- fetch of one span (frames w..w+3 of the signal at xb) into registers ----
@@ -155,11 +156,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
         if (inside && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
 #pragma unroll
             for (int q = 0; q < NV; ++q) {
-#if R512F_NT_LOAD
-                pre[q] = __builtin_nontemporal_load(reinterpret_cast<const TV *>(src) + (q * 64 + lane));
-#else
-                pre[q] = reinterpret_cast<const TV *>(src)[q * 64 + lane];
-#endif
+                // only 3*hop + 32*NR samples are ever read by pass 1: lanes past that re-read the last
+                // needed vector (same cache line, no extra traffic) so that the number of loads stays fixed
+                pre[q] = reinterpret_cast<const TV *>(src)[min(q * 64 + lane, nvec - 1)];
             }
         } else {
             FrameDesc d{};

@@ -222,6 +222,7 @@ int family_of(size_t nfft)
     if (nfft < 2) { return 0; }
     if (!is_pow2(nfft)) { return 1; }
     if (nfft == 512 && !g_force_generic.load()) { return 3; }
+    if (nfft == 4096 && sizeof(T) == 4 && !g_force_generic.load()) { return 4; }
     return 2;
 }
 
@@ -242,6 +243,12 @@ int run_fused(const char *fn, int dev, T *Yd, const T *Xd, const T *wd, const Fr
     if (fam == 3 && r512_supported<T>(d)) {
         HIPCHK(fn, launch_stft_r512<T>(Yd, Xd, wd, tw, d, s));
         return 0;
+    }
+    if constexpr (sizeof(T) == 4) {
+        if (fam == 4 && r4096_supported(d)) {
+            HIPCHK(fn, launch_stft_r4096(Yd, Xd, wd, tw, d, s));
+            return 0;
+        }
     }
     if (nfft * sizeof(T) > LDS_LIMIT) { fprintf(stderr, "error in %s: nfft too large (limit %zu)\n", fn, LDS_LIMIT / sizeof(T)); return 1; }
     HIPCHK(fn, launch_stft_pow2<T>(Yd, Xd, wd, tw, d, s));

@@ -109,7 +109,7 @@ int dsp_fft_power_dev_z (double *Y_dev, const double *X_dev, const size_t N, voi
 
 /* Which kernel family the fused path would use for (nfft, element size 4 or 8):
  * 0 = none (invalid), 1 = direct DFT (nfft not a power of two), 2 = generic power-of-two,
- * 3 = register-resident 512-point.  For tests and benchmarks. */
+ * 3 = register-resident 512-point, 4 = register-resident 4096-point (float32).  For tests and benchmarks. */
 int dsp_stft_kernel_family (const size_t nfft, const size_t elem_size);
 
 /* Forces the generic kernel family (2, or 1 for non-powers-of-two) when on != 0; for A/B tests. */

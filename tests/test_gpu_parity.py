@@ -114,6 +114,46 @@ def test_both_512_families_agree_with_oracle(O, D, dt):
             check_spec(O, Y, Yref)
 
 
+def test_both_4096_families_agree_with_oracle(O, D):
+    """nfft 4096 (float32) has a register-resident kernel beside the generic one; each must meet the
+    bound on its own: full and short windows, odd hop (unaligned frame starts), a signal shorter
+    than the window (repeated reflection), every flag, and the zero-edged stft_flt framing."""
+    dt = np.float32
+    assert D.kernel_family(4096, dt) == 4
+    for (N, L, stp, flags) in [(40000, 4096, 1024, (0, 0, 0)), (40001, 4096, 1023, (1, 0, 0)), (30000, 3000, 700, (0, 1, 0)),
+                               (30000, 2049, 512, (1, 1, 1)), (3000, 4096, 1024, (0, 0, 1)), (20000, 100, 5000, (1, 0, 0)),
+                               (9000, 4095, 1, (0, 0, 0))]:
+        x = signal(N + L, N, dt) + dt(0.2)
+        win = D.blackmanharris(L, dt) if L > 3000 else D.povey(L, dt)
+        if stp == 1:
+            x = x[:4200]
+        for snip in (0, 1):
+            if snip and L > len(x):
+                continue
+            # float64 FFT oracle on the same (exactly representable) inputs
+            rc, Yref = O.stft(x.astype(np.float64), win.astype(np.float64), stp, 4096, snip, *flags, exact=False)
+            assert rc == 0
+            for generic in (False, True):
+                D.force_generic(generic)
+                try:
+                    Y = D.stft(x, win, stp, bool(snip), *[bool(f) for f in flags], nfft=4096)
+                finally:
+                    D.force_generic(False)
+                check_spec(O, Y, Yref.astype(dt), flags[1], flags[2])
+    x = signal(77, 30000, dt)
+    win = D.blackmanharris(4096, dt)
+    for intended in (False, True):
+        D.set_flt_mode(intended)
+        try:
+            for (c0, stp, W) in [(0.0, 1024.0, 30), (3000.0, 1000.5, 20), (-6000.0, 2048.0, 20)]:
+                rc, Yref = O.stft_flt(x.astype(np.float64), win.astype(np.float64), W, c0, stp, 4096, 0, 0, 0, intended=intended, exact=False)
+                assert rc == 0
+                Y = D.stft_flt(x, win, W, c0, stp, nfft=4096)
+                check_spec(O, Y, Yref.astype(dt))
+        finally:
+            D.set_flt_mode(False)
+
+
 @pytest.mark.parametrize("tag", ["s", "d"])
 def test_stft_against_reference_fixtures(O, D, tag):
     """Fixtures hold what the reference's own frame_univar -> apply_win -> FFT -> fft_power returned."""

@@ -56,6 +56,80 @@ __device__ __forceinline__ void dft16(T (&re)[16], T (&im)[16])
 }
 __host__ __device__ constexpr int slot16(int k) { return 4 * (k & 3) + (k >> 2); }
 
+// ---- the same transforms on (re, im) pairs ------------------------------------------------------
+// A complex value is one 2-element vector, so that float arithmetic maps to the packed two-lane
+// instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: one issue slot for both components; the
+// swaps and sign flips below become their op_sel / neg modifiers).  A plain float instruction costs
+// the same issue slot for one component, so this halves the instruction count of the butterflies.
+// For double the same source compiles to scalar f64 instructions.
+typedef float cxf __attribute__((ext_vector_type(2)));
+struct cxd { double x, y; };
+__device__ __forceinline__ cxd operator+(const cxd a, const cxd b) { return cxd{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cxd operator-(const cxd a, const cxd b) { return cxd{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cxd operator*(const cxd a, const cxd b) { return cxd{a.x * b.x, a.y * b.y}; }   // element-wise
+__device__ __forceinline__ cxd &operator+=(cxd &a, const cxd b) { a.x += b.x; a.y += b.y; return a; }
+__device__ __forceinline__ cxd &operator-=(cxd &a, const cxd b) { a.x -= b.x; a.y -= b.y; return a; }
+template <typename T> struct cx_of;
+template <> struct cx_of<float> { using type = cxf; };
+template <> struct cx_of<double> { using type = cxd; };
+template <typename T> using cx = typename cx_of<T>::type;
+
+__device__ __forceinline__ cxf cx_swap(const cxf a) { return __builtin_shufflevector(a, a, 1, 0); }
+__device__ __forceinline__ cxd cx_swap(const cxd a) { return cxd{a.y, a.x}; }
+__device__ __forceinline__ cxf cx_fma(const cxf a, const cxf b, const cxf c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ cxd cx_fma(const cxd a, const cxd b, const cxd c) { return cxd{fma(a.x, b.x, c.x), fma(a.y, b.y, c.y)}; }
+// a - i b and a + i b
+template <typename T> __device__ __forceinline__ cx<T> cx_sub_i(const cx<T> a, const cx<T> b) { return cx_fma(cx_swap(b), cx<T>{T(1), T(-1)}, a); }
+template <typename T> __device__ __forceinline__ cx<T> cx_add_i(const cx<T> a, const cx<T> b) { return cx_fma(cx_swap(b), cx<T>{T(-1), T(1)}, a); }
+// a + conj(b) and a - conj(b)
+template <typename T> __device__ __forceinline__ cx<T> cx_add_conj(const cx<T> a, const cx<T> b) { return cx_fma(b, cx<T>{T(1), T(-1)}, a); }
+template <typename T> __device__ __forceinline__ cx<T> cx_sub_conj(const cx<T> a, const cx<T> b) { return cx_fma(b, cx<T>{T(-1), T(1)}, a); }
+// a * (c + i s)
+template <typename T> __device__ __forceinline__ cx<T> cx_mul(const cx<T> a, const T c, const T s)
+{
+    const cx<T> t = a * cx<T>{c, c};
+    return cx_fma(cx_swap(a), cx<T>{-s, s}, t);
+}
+template <typename T> __device__ __forceinline__ cx<T> cx_mul(const cx<T> a, const cx<T> w) { return cx_mul<T>(a, w.x, w.y); }
+// |a|^2
+template <typename T> __device__ __forceinline__ T cx_norm(const cx<T> a) { const cx<T> q = a * a; return q.x + q.y; }
+
+template <typename T, bool Z3 = false>
+__device__ __forceinline__ void dft4c(cx<T> &a0, cx<T> &a1, cx<T> &a2, cx<T> &a3)
+{
+    const cx<T> s0 = a0 + a2, s1 = a0 - a2;
+    const cx<T> s2 = Z3 ? a1 : a1 + a3, t = Z3 ? a1 : a1 - a3;
+    a0 = s0 + s2;
+    a2 = s0 - s2;
+    a1 = cx_sub_i<T>(s1, t);
+    a3 = cx_add_i<T>(s1, t);
+}
+
+// dft16 on pairs: same index map, same output slots, same known-zero rows
+template <typename T, int NZ = 16>
+__device__ __forceinline__ void dft16c(cx<T> (&z)[16])
+{
+    static_assert(NZ >= 13 && NZ <= 16, "only the last row of each column may be known-zero");
+    constexpr T C1 = T(0.92387953251128675612818318939678829L);   // cos(pi/8)
+    constexpr T S1 = T(0.38268343236508977172845998403039887L);   // sin(pi/8)
+    constexpr T R2 = T(0.70710678118654752440084436210484904L);   // sqrt(1/2)
+    dft4c<T, (NZ <= 12)>(z[0], z[4], z[8], z[12]);
+    dft4c<T, (NZ <= 13)>(z[1], z[5], z[9], z[13]);
+    dft4c<T, (NZ <= 14)>(z[2], z[6], z[10], z[14]);
+    dft4c<T, (NZ <= 15)>(z[3], z[7], z[11], z[15]);
+    z[5] = cx_mul<T>(z[5], C1, -S1);       // W16^1
+    z[6] = cx_mul<T>(z[6], R2, -R2);       // W16^2
+    z[7] = cx_mul<T>(z[7], S1, -C1);       // W16^3
+    z[9] = cx_mul<T>(z[9], R2, -R2);       // W16^2
+    z[10] = cx_swap(z[10]) * cx<T>{T(1), T(-1)};   // W16^4 = -i
+    z[11] = cx_mul<T>(z[11], -R2, -R2);    // W16^6
+    z[13] = cx_mul<T>(z[13], S1, -C1);     // W16^3
+    z[14] = cx_mul<T>(z[14], -R2, -R2);    // W16^6
+    z[15] = cx_mul<T>(z[15], -C1, S1);     // W16^9
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) { dft4c<T>(z[4 * k1], z[4 * k1 + 1], z[4 * k1 + 2], z[4 * k1 + 3]); }
+}
+
 constexpr int R512_EXF = 16 * 17;   // complex slots per frame in the exchange region (row pitch 17)
 
 }  // namespace dsp

@@ -2,18 +2,23 @@
 // [mean removal] + real FFT + power + [sqrt][log], one wavefront per frame.
 //
 // The 4096 real samples of a frame are packed as 2048 complex points z_n = x_2n + i x_2n+1 and
-// transformed as 32 x 64:
+// transformed as 32 x 64, every complex value one (re, im) register pair so that the butterflies
+// run on the packed two-component float instructions:
 //   pass 1  lane n2 (0..63) loads its 32 points z[64 n1 + n2] straight from global memory (for a
 //           fixed n1 the wave reads 512 contiguous bytes), multiplies by the window (LDS table),
 //           runs a 32-point FFT over n1 in registers and multiplies by W2048^(n2 k1);
-//   exchange through LDS (32 rows of pitch 66 complex: conflict-free 8-byte writes and reads);
-//   pass 2  lane (k1, h) runs a 32-point FFT over the n2 of parity h; the two halves of the
-//           64-point transform are combined with the neighbouring lane by one DPP quad swap;
+//   radix-2 the first (decimation-in-frequency) stage of the 64-point transforms over n2 pairs lane
+//           n2 with lane n2 + 32: one v_permlane32_swap per register hands rows k1 < 16 to the lower
+//           half-wave and rows k1 >= 16 to the upper one, each lane then holding both inputs of its
+//           butterfly; u = x + y feeds the even outputs, v = (x - y) W64^n2 the odd ones;
+//   exchange through LDS: 64 rows (k1, parity) of 32 values, pitch 33 (conflict-free both ways);
+//   pass 2  lane (k1, parity) runs one 32-point FFT and holds Z[k1 + 32 parity + 64 k'];
 //   split   Z goes to LDS once, each lane reads bins k and 2048-k, and the real-FFT split is fused
 //           with the power step; rows are stored as whole 256-byte wave stores.
-// Frames are dealt round-robin inside 8 contiguous ranges (one per group of workgroups that share an
-// XCD), so the 3/4 of a frame that overlaps its neighbours is served by that XCD's L2 and every
-// sample is fetched from HBM once.
+// The next frame's samples are requested as soon as the registers are free (under the split and
+// the stores).  Frames are dealt round-robin inside 8 contiguous ranges (one per group of
+// workgroups that share an XCD), so the 3/4 of a frame that overlaps its neighbours is served by
+// that XCD's L2 and every sample is fetched from HBM once.
 #include "stft_common.h"
 #include "fft16.h"
 #include <cstdlib>
@@ -31,31 +36,59 @@ struct R4096Args {
     int frames;           // B * W
 };
 
-constexpr int R4096_PITCH = 66;                         // complex slots per exchange row
-constexpr int R4096_WAVE_C = 32 * R4096_PITCH;          // complex slots per wave (>= 2048 + 8)
+constexpr int R4096_PITCH = 33;                         // complex slots per exchange row
+constexpr int R4096_WAVE_C = 64 * R4096_PITCH;          // complex slots per wave (>= 2048)
 constexpr int R4096_WAVES = 8;                          // waves per workgroup (share the window table)
+typedef float2 __attribute__((aligned(4))) float2_u;    // frame starts are only 4-byte aligned
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+
+#ifndef R4096_ABLATE
+#define R4096_ABLATE 0          // diagnostic builds: bit 0 = no row stores, bit 1 = no sample loads
+#endif
+#ifndef R4096_STAMPS
+#define R4096_STAMPS 0          // diagnostic builds: 1 = per-phase s_memtime sums into g_r4096_stamps
+#endif
+#if R4096_STAMPS
+__device__ unsigned long long g_r4096_stamps[2048 * 8];
+#define R4096_STAMP(i)                                                                            \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        unsigned long long t_;                                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");             \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        st_acc[i] += t_ - st_last; st_last = t_;                                                  \
+    } while (0)
+#else
+#define R4096_STAMP(i) do {} while (0)
+#endif
 
 // W32^k, k < 16, and W64^k, k < 32, as (cos, -sin)(2 pi k / n) pairs; indexed with compile-time
 // constants only, so they fold into the instructions as literals
 __device__ constexpr float W32C[32] = {1.000000000e+00f, -0.000000000e+00f, 9.807852507e-01f, -1.950903237e-01f, 9.238795042e-01f, -3.826834261e-01f, 8.314695954e-01f, -5.555702448e-01f, 7.071067691e-01f, -7.071067691e-01f, 5.555702448e-01f, -8.314695954e-01f, 3.826834261e-01f, -9.238795042e-01f, 1.950903237e-01f, -9.807852507e-01f, 6.123234263e-17f, -1.000000000e+00f, -1.950903237e-01f, -9.807852507e-01f, -3.826834261e-01f, -9.238795042e-01f, -5.555702448e-01f, -8.314695954e-01f, -7.071067691e-01f, -7.071067691e-01f, -8.314695954e-01f, -5.555702448e-01f, -9.238795042e-01f, -3.826834261e-01f, -9.807852507e-01f, -1.950903237e-01f};
 __device__ constexpr float W64C[64] = {1.000000000e+00f, -0.000000000e+00f, 9.951847196e-01f, -9.801714122e-02f, 9.807852507e-01f, -1.950903237e-01f, 9.569403529e-01f, -2.902846634e-01f, 9.238795042e-01f, -3.826834261e-01f, 8.819212914e-01f, -4.713967443e-01f, 8.314695954e-01f, -5.555702448e-01f, 7.730104327e-01f, -6.343932748e-01f, 7.071067691e-01f, -7.071067691e-01f, 6.343932748e-01f, -7.730104327e-01f, 5.555702448e-01f, -8.314695954e-01f, 4.713967443e-01f, -8.819212914e-01f, 3.826834261e-01f, -9.238795042e-01f, 2.902846634e-01f, -9.569403529e-01f, 1.950903237e-01f, -9.807852507e-01f, 9.801714122e-02f, -9.951847196e-01f, 6.123234263e-17f, -1.000000000e+00f, -9.801714122e-02f, -9.951847196e-01f, -1.950903237e-01f, -9.807852507e-01f, -2.902846634e-01f, -9.569403529e-01f, -3.826834261e-01f, -9.238795042e-01f, -4.713967443e-01f, -8.819212914e-01f, -5.555702448e-01f, -8.314695954e-01f, -6.343932748e-01f, -7.730104327e-01f, -7.071067691e-01f, -7.071067691e-01f, -7.730104327e-01f, -6.343932748e-01f, -8.314695954e-01f, -5.555702448e-01f, -8.819212914e-01f, -4.713967443e-01f, -9.238795042e-01f, -3.826834261e-01f, -9.569403529e-01f, -2.902846634e-01f, -9.807852507e-01f, -1.950903237e-01f, -9.951847196e-01f, -9.801714122e-02f};
 
+using C2 = cx<float>;
+
 // forward 32-point DFT of x[n], n = 0..31, given as even part e[m] = x[2m] and odd part o[m] = x[2m+1].
 // On return X[k] is in e[slot16(k)] for k < 16 and in o[slot16(k - 16)] for k >= 16.
-__device__ __forceinline__ void dft32(float (&er)[16], float (&ei)[16], float (&orr)[16], float (&oi)[16])
+__device__ __forceinline__ void dft32c(C2 (&e)[16], C2 (&o)[16])
 {
-    dft16<float, 16>(er, ei);
-    dft16<float, 16>(orr, oi);
+    dft16c<float, 16>(e);
+    dft16c<float, 16>(o);
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int s = slot16(k);
-        float tr = orr[s], ti = oi[s];
-        if (k == 8) { const float t = tr; tr = ti; ti = -t; }
-        else if (k > 0) { cmul(tr, ti, W32C[2 * k], W32C[2 * k + 1]); }
-        orr[s] = er[s] - tr; oi[s] = ei[s] - ti;
-        er[s] += tr; ei[s] += ti;
+        C2 t = o[s];
+        if (k == 8) { t = cx_swap(t) * C2{1.f, -1.f}; }
+        else if (k > 0) { t = cx_mul<float>(t, W32C[2 * k], W32C[2 * k + 1]); }
+        o[s] = e[s] - t;
+        e[s] = e[s] + t;
     }
 }
+
+// position of Z[k] in the wave's tile: the upper half of every 64-block is shifted by 8 inside
+// itself, which spreads the two half-blocks a wave store touches over all banks
+__device__ __forceinline__ int zpos(int k) { return k ^ (((k >> 5) & 1) << 3); }
 
 template <bool FULL, bool MN0, bool EPI>
 __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *__restrict__ Y, const float *__restrict__ X,
@@ -68,164 +101,228 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int L = a.L;
     float *wtab = reinterpret_cast<float *>(smem_raw);                               // halved window, 4096 floats
-    float2 *ex = reinterpret_cast<float2 *>(wtab + 4096) + wv * R4096_WAVE_C;         // this wave's tile
+    C2 *ex = reinterpret_cast<C2 *>(wtab + 4096) + wv * R4096_WAVE_C;                 // this wave's tile
 
     for (int l = tid; l < 4096; l += 64 * R4096_WAVES) { wtab[l] = (l < L) ? 0.5f * win[l] : 0.0f; }
 
-    // per-lane twiddles: W2048^(lane b), b = 1..3, and W2048^(4 lane a), a = 1..7; W4096^lane for the split
-    auto tw2048 = [&](int m, float &c, float &s) {       // W2048^m = W4096^(2m), table holds k < 2048
+    // per-lane twiddles: W2048^(lane b), b = 1..3, and W2048^(4 lane a), a = 1..7
+    auto tw2048 = [&](int m) {                            // W2048^m = W4096^(2m), table holds k < 2048
         int idx = (2 * m) & 4095;
         float sg = 1.0f;
         if (idx >= 2048) { idx -= 2048; sg = -1.0f; }
-        c = sg * tw[2 * idx]; s = sg * tw[2 * idx + 1];
+        return C2{sg * tw[2 * idx], sg * tw[2 * idx + 1]};
     };
-    float tbr[4], tbi[4], tar[8], tai[8];
+    C2 tb[4], ta[8];
 #pragma unroll
-    for (int b = 1; b < 4; ++b) { tw2048(lane * b, tbr[b], tbi[b]); }
+    for (int b = 1; b < 4; ++b) { tb[b] = tw2048(lane * b); }
 #pragma unroll
-    for (int q = 1; q < 8; ++q) { tw2048(4 * lane * q, tar[q], tai[q]); }
-    const float owr = tw[2 * lane], owi = tw[2 * lane + 1];            // W4096^lane
-    const int k1p = lane >> 1, hp = lane & 1;                          // pass-2 role of the lane
-    const float sgn = hp ? -1.0f : 1.0f;
+    for (int q = 1; q < 8; ++q) { ta[q] = tw2048(4 * lane * q); }
+    const int n2h = lane & 31, up = lane >> 5;
+    const C2 wl = C2{tw[2 * 64 * n2h], tw[2 * 64 * n2h + 1]};          // W64^(lane % 32)
+    const C2 owm = C2{tw[2 * lane + 1], -tw[2 * lane]};                // -i W4096^lane, for the split
     __syncthreads();
 
     // frames: 8 contiguous ranges by blockIdx % 8, round-robin over the waves inside a range
     const int xcd = blockIdx.x & 7, nwg_x = gridDim.x >> 3;
     const int f_lo = (int)((long long)a.frames * xcd / 8), f_hi = (int)((long long)a.frames * (xcd + 1) / 8);
     const int fstride = nwg_x * R4096_WAVES;
+    int fid = f_lo + (blockIdx.x >> 3) * R4096_WAVES + wv;
+    if (fid >= f_hi) { return; }
 
-    for (int fid = f_lo + (blockIdx.x >> 3) * R4096_WAVES + wv; fid < f_hi; fid += fstride) {
-        const int b = fid / a.W;
-        const int w = fid - b * a.W;
-        const float *xb = X + (long long)b * a.ldx;
-        long long ss, rdoff;
-        if (a.tbl) { ss = a.tbl[2 * w]; rdoff = ss - (long long)a.tbl[2 * w + 1]; }
-        else { ss = a.ss0 + (long long)w * a.stp; rdoff = a.rd_shift; }
+    // where frame f lies: output row, first sample, and whether all 4096 samples can be read in place
+    struct Where { long long row; const float *xb; long long ss, rdoff; bool inside; };
+    auto locate = [&](int f) {
+        Where q;
+        const int b = f / a.W;
+        const int w = f - b * a.W;
+        q.row = (long long)b * a.W + w;
+        q.xb = X + (long long)b * a.ldx;
+        if (a.tbl) { q.ss = a.tbl[2 * w]; q.rdoff = q.ss - (long long)a.tbl[2 * w + 1]; }
+        else { q.ss = a.ss0 + (long long)w * a.stp; q.rdoff = a.rd_shift; }
+        if (!a.edge) { q.rdoff = 0; }
+        q.inside = q.ss >= 0 && q.ss + 4096 <= a.N && q.ss >= q.rdoff;
+        return q;
+    };
+    C2 ze[16], zo[16];                              // even / odd rows of the 32-point transforms
+    // raw samples of a frame that lies inside its signal: 32 coalesced 512-byte wave loads
+    auto load_inside = [&](const Where &q) {
+        const float *src = q.xb + (q.ss - q.rdoff) + 2 * lane;
+#pragma unroll
+        for (int n1 = 0; n1 < 32; ++n1) {
+            float2 v = make_float2(0.f, 0.f);
+#if R4096_ABLATE & 2
+            if (a.N == -12345)
+#endif
+            if (FULL || 128 * n1 < L) { v = *reinterpret_cast<const float2_u *>(src + 128 * n1); }
+            if (n1 & 1) { zo[n1 >> 1] = C2{v.x, v.y}; } else { ze[n1 >> 1] = C2{v.x, v.y}; }
+        }
+    };
+    // a frame that crosses an edge of its signal: gather sample by sample into the (idle) tile first
+    auto load_edge = [&](const Where &q) {
+        FrameDesc d{};
+        d.N = a.N; d.edge = a.edge;
+        float *stage = reinterpret_cast<float *>(ex);
+        wave_sync();
+        for (int l = lane; l < 4096; l += 64) { stage[l] = (l < L) ? fetch_sample(q.xb, d, q.ss, q.rdoff, l) : 0.f; }
+        wave_sync();
+#pragma unroll
+        for (int n1 = 0; n1 < 32; ++n1) {
+            const float2 v = *reinterpret_cast<const float2 *>(stage + 128 * n1 + 2 * lane);
+            if (n1 & 1) { zo[n1 >> 1] = C2{v.x, v.y}; } else { ze[n1 >> 1] = C2{v.x, v.y}; }
+        }
+        asm volatile("" ::: "memory");                 // keeps these LDS reads from being merged with load_inside's into flat loads
+    };
 
-        // ---------------- pass 1: load, window, 32-point FFT over n1 ----------------
-        float er[16], ei[16], orr[16], oi[16];          // even / odd n1
+    Where cur = locate(fid);
+    if (cur.inside) { load_inside(cur); } else { load_edge(cur); }
+#if R4096_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory");
+#endif
+
+    // One frame: transform the samples in the registers, start the next frame's loads, write the row.
+    // Returns false after the last frame.  The first frame runs in a copy of its own, so that inside
+    // the loop every wait on the prefetched samples sees the same sequence of loads followed by this
+    // frame's stores and lets the stores drain in the background.
+    auto frame = [&]() __attribute__((always_inline)) -> bool {
+        // ---------------- pass 1: window, 32-point FFT over n1 ----------------
         {
-            const float *src = xb + (ss - (a.edge ? rdoff : 0)) + 2 * lane;
-            const bool inside = ss >= 0 && ss + 4096 <= a.N && (a.edge == 0 || ss >= rdoff) &&
-                                ((reinterpret_cast<uintptr_t>(src) & 7) == 0);
-            if (inside) {
-#pragma unroll
-                for (int n1 = 0; n1 < 32; ++n1) {
-                    float2 v = make_float2(0.f, 0.f);
-                    if (FULL || 128 * n1 < L) { v = *reinterpret_cast<const float2 *>(src + 128 * n1); }
-                    if (n1 & 1) { orr[n1 >> 1] = v.x; oi[n1 >> 1] = v.y; } else { er[n1 >> 1] = v.x; ei[n1 >> 1] = v.y; }
-                }
-            } else {
-                FrameDesc d{};
-                d.N = a.N; d.edge = a.edge;
-#pragma unroll
-                for (int n1 = 0; n1 < 32; ++n1) {
-                    const int l = 128 * n1 + 2 * lane;
-                    const float p = (l < L) ? fetch_sample(xb, d, ss, rdoff, l) : 0.f;
-                    const float c = (l + 1 < L) ? fetch_sample(xb, d, ss, rdoff, l + 1) : 0.f;
-                    if (n1 & 1) { orr[n1 >> 1] = p; oi[n1 >> 1] = c; } else { er[n1 >> 1] = p; ei[n1 >> 1] = c; }
-                }
-            }
-            float sum = 0.f;
+            C2 acc = C2{0.f, 0.f};
+            int lim = L - 2 * lane;                          // sample l = 128 n1 + 2 lane is inside the window iff 128 n1 < lim
+            asm volatile("" : "+v"(lim));                    // recomputed per frame: 64 hoisted lane masks would not fit in SGPRs
 #pragma unroll
             for (int n1 = 0; n1 < 32; ++n1) {
-                const float2 h = *reinterpret_cast<const float2 *>(wtab + 128 * n1 + 2 * lane);
-                float &p = (n1 & 1) ? orr[n1 >> 1] : er[n1 >> 1];
-                float &c = (n1 & 1) ? oi[n1 >> 1] : ei[n1 >> 1];
+                const float2 hh = *reinterpret_cast<const float2 *>(wtab + 128 * n1 + 2 * lane);
+                C2 &z = (n1 & 1) ? zo[n1 >> 1] : ze[n1 >> 1];
                 if (!FULL) {                                 // keep data past the window out (0 * NaN)
-                    const int l = 128 * n1 + 2 * lane;
-                    p = (l < L) ? p : 0.f;
-                    c = (l + 1 < L) ? c : 0.f;
+                    z.x = (128 * n1 < lim) ? z.x : 0.f;
+                    z.y = (128 * n1 + 1 < lim) ? z.y : 0.f;
                 }
-                p *= h.x; c *= h.y;
-                if (MN0) { sum += p + c; }
+                z = z * C2{hh.x, hh.y};
+                if (MN0) { acc += z; }
             }
             if (MN0) {
+                float sum = acc.x + acc.y;
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) { sum += __shfl_xor(sum, o); }
                 const float mean = sum / (float)L;
 #pragma unroll
                 for (int n1 = 0; n1 < 32; ++n1) {
-                    const int l = 128 * n1 + 2 * lane;
-                    float &p = (n1 & 1) ? orr[n1 >> 1] : er[n1 >> 1];
-                    float &c = (n1 & 1) ? oi[n1 >> 1] : ei[n1 >> 1];
-                    p -= (FULL || l < L) ? mean : 0.f;
-                    c -= (FULL || l + 1 < L) ? mean : 0.f;
+                    C2 &z = (n1 & 1) ? zo[n1 >> 1] : ze[n1 >> 1];
+                    z -= C2{(FULL || 128 * n1 < lim) ? mean : 0.f, (FULL || 128 * n1 + 1 < lim) ? mean : 0.f};
                 }
             }
         }
-        dft32(er, ei, orr, oi);
+        dft32c(ze, zo);
+        R4096_STAMP(0);
 
-        // twiddle W2048^(lane k1), k1 = 4 q + b, and write row k1 of the tile
-        wave_sync();                                       // the previous frame's reads of the tile are done
+        // twiddle W2048^(lane k1), k1 = 4 q + b
 #pragma unroll
-        for (int k1 = 0; k1 < 32; ++k1) {
-            float r = (k1 < 16) ? er[slot16(k1)] : orr[slot16(k1 - 16)];
-            float i = (k1 < 16) ? ei[slot16(k1)] : oi[slot16(k1 - 16)];
+        for (int k1 = 1; k1 < 32; ++k1) {
+            C2 &z = (k1 < 16) ? ze[slot16(k1)] : zo[slot16(k1 - 16)];
             const int q = k1 >> 2, bb = k1 & 3;
-            if (bb) { cmul(r, i, tbr[bb], tbi[bb]); }
-            if (q) { cmul(r, i, tar[q], tai[q]); }
-            ex[k1 * R4096_PITCH + lane] = make_float2(r, i);
+            if (bb) { z = cx_mul<float>(z, tb[bb]); }
+            if (q) { z = cx_mul<float>(z, ta[q]); }
+        }
+        // first radix-2 stage of the 64-point transforms over n2, rows k1 and k1 + 16 in one swap:
+        // afterwards the lower half-wave holds row k1 (x = column n2, y = column n2 + 32), the upper
+        // half-wave row k1 + 16
+        wave_sync();                                       // the previous frame's reads of the tile are done
+        {
+            C2 *dst = ex + (32 * up) * R4096_PITCH + n2h;  // rows 2 k1 + parity, k1 = a + 16 up
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) {
+                const C2 lo = ze[slot16(k1)], hi = zo[slot16(k1)];
+                const u2v sr = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo.x), __float_as_uint(hi.x), false, false);
+                const u2v si = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo.y), __float_as_uint(hi.y), false, false);
+                const C2 x = C2{__uint_as_float(sr.x), __uint_as_float(si.x)};
+                const C2 y = C2{__uint_as_float(sr.y), __uint_as_float(si.y)};
+                dst[(2 * k1) * R4096_PITCH] = x + y;
+                dst[(2 * k1 + 1) * R4096_PITCH] = cx_mul<float>(x - y, wl);
+            }
         }
         wave_sync();
+        R4096_STAMP(1);
 
-        // ---------------- pass 2: 32-point FFT over the n2 of parity hp, then the 64-point combine ----------------
+        // ---------------- pass 2: lane = row (k1, parity): 32-point FFT ----------------
         {
-            const float2 *row = ex + k1p * R4096_PITCH + hp;
+            const C2 *row = ex + lane * R4096_PITCH;
 #pragma unroll
             for (int m = 0; m < 32; ++m) {
-                const float2 v = row[2 * m];
-                if (m & 1) { orr[m >> 1] = v.x; oi[m >> 1] = v.y; } else { er[m >> 1] = v.x; ei[m >> 1] = v.y; }
+                if (m & 1) { zo[m >> 1] = row[m]; } else { ze[m >> 1] = row[m]; }
             }
         }
-        dft32(er, ei, orr, oi);
+        dft32c(ze, zo);
+        R4096_STAMP(2);
         wave_sync();                                       // every lane has its row: the tile becomes Z
         {
-            float2 *zrow = ex + k1p + hp * (1024 + 8);     // Z[k] sits at k + 8 (k >= 1024): conflict-free halves
+            C2 *zdst = ex + zpos((lane >> 1) + 32 * (lane & 1));   // Z[k1 + 32 parity + 64 k']
 #pragma unroll
-            for (int k2 = 0; k2 < 32; ++k2) {
-                float gr = (k2 < 16) ? er[slot16(k2)] : orr[slot16(k2 - 16)];
-                float gi = (k2 < 16) ? ei[slot16(k2)] : oi[slot16(k2 - 16)];
-                // odd-parity lanes carry G1 and multiply it by W64^k2; then X[k2] = G0 + W G1 (even lane),
-                // X[k2 + 32] = G0 - W G1 (odd lane) after one swap with the neighbouring lane
-                float tr = gr, ti = gi;
-                if (k2 == 16) { const float t = tr; tr = ti; ti = -t; }
-                else if (k2 > 0) { cmul(tr, ti, W64C[2 * k2], W64C[2 * k2 + 1]); }
-                gr = hp ? tr : gr; gi = hp ? ti : gi;
-                const float pr = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(gr), 0xB1, 0xf, 0xf, false));
-                const float pi = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(gi), 0xB1, 0xf, 0xf, false));
-                zrow[32 * k2] = make_float2(fmaf(gr, sgn, pr), fmaf(gi, sgn, pi));
+            for (int kp = 0; kp < 32; ++kp) {
+                zdst[64 * kp] = (kp < 16) ? ze[slot16(kp)] : zo[slot16(kp - 16)];
             }
         }
         wave_sync();
+        R4096_STAMP(3);
+
+        // the registers are free from here on: start the next frame's loads under the split
+        const int nfid = fid + fstride;
+        const bool more = nfid < f_hi;
+        const Where nxt = locate(more ? nfid : fid);
+        if (nxt.inside) { load_inside(nxt); }
+        R4096_STAMP(4);
 
         // ---------------- split + power + store: lane handles bins k = lane + 64 m and 2048 - k ----------------
-        float *y = Y + ((long long)b * a.W + w) * F;
+        float *y = Y + cur.row * F;
+        const C2 *zk = ex + zpos(lane);
+        const C2 *zmk = ex + (lane == 0 ? 64 * 17 : zpos(M - lane) - 64 * 15);     // Z[2048 - lane - 64 m] at zmk[64 (15 - m)]
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
             const int k = lane + 64 * m;
-            const float2 z = ex[k];
-            const int km = (m == 0 && lane == 0) ? 0 : (M + 8 - k);
-            const float2 zm = ex[km];
-            const float ar = z.x + zm.x, ai = z.y - zm.y, br = z.x - zm.x, bi = z.y + zm.y;
+            const C2 z = zk[64 * m];
+            const C2 zm = (m == 0) ? ((lane == 0) ? z : zmk[64 * 15]) : zmk[64 * (15 - m)];
+            const C2 A = cx_add_conj<float>(z, zm);
+            C2 B = cx_sub_conj<float>(z, zm);
             // -i W4096^k B with W4096^k = W4096^lane W64^m
-            float ur = br, ui = bi;
-            if (m > 0) { cmul(ur, ui, W64C[2 * m], W64C[2 * m + 1]); }
-            const float tr = ur * owi + ui * owr, ti = ui * owi - ur * owr;
-            const float pr = ar + tr, pi = ai + ti, qr = ar - tr, qi = ai - ti;
-            float p = pr * pr + pi * pi, q = qr * qr + qi * qi;
+            if (m > 0) { B = cx_mul<float>(B, W64C[2 * m], W64C[2 * m + 1]); }
+            const C2 Tw = cx_mul<float>(B, owm);
+            float p = cx_norm<float>(A + Tw), q = cx_norm<float>(A - Tw);
             if (EPI) { p = power_epilogue(p, a.amp, a.lg); q = power_epilogue(q, a.amp, a.lg); }
-            y[k] = p;
-            y[M - k] = q;
+#if R4096_ABLATE & 1
+            asm volatile("" :: "v"(p), "v"(q));
+            if (a.N == -12345)
+#endif
+            { y[k] = p; y[M - k] = q; }
         }
         if (lane == 0) {
-            const float2 z = ex[1024 + 8];                 // bin 1024 pairs with itself (Z holds half values)
-            float p = 4.0f * (z.x * z.x + z.y * z.y);
+            float p = 4.0f * cx_norm<float>(ex[1024]);     // bin 1024 pairs with itself (Z holds half values)
             if (EPI) { p = power_epilogue(p, a.amp, a.lg); }
             y[1024] = p;
         }
+        R4096_STAMP(5);
+        if (!more) { return false; }
+        if (!nxt.inside) { load_edge(nxt); }
+        cur = nxt;
+        fid = nfid;
+        return true;
+    };
+#if R4096_STAMPS
+    if (frame()) { while (frame()) { } }
+    if (lane == 0) {
+        const int gw = blockIdx.x * R4096_WAVES + wv;
+        if (gw < 2048) { for (int i = 0; i < 8; ++i) { g_r4096_stamps[gw * 8 + i] = st_acc[i]; } }
     }
+#else
+    if (!frame()) { return; }
+    while (frame()) { }
+#endif
 }
+#if R4096_STAMPS
+extern "C" int dsp_debug_read_stamps4096(unsigned long long *dst, size_t n)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_r4096_stamps), n * sizeof(unsigned long long));
+}
+#endif
 
 
 bool r4096_supported(const FrameDesc &d)

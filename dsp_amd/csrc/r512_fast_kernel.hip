@@ -84,6 +84,12 @@ __device__ unsigned long long g_r512f_stamps[8192 * 8];
 #else
 #define R512F_STAMP(i) do {} while (0)
 #endif
+#ifndef R512F_OPAQUE_TW
+#define R512F_OPAQUE_TW 0
+#endif
+#ifndef R512F_ST4
+#define R512F_ST4 0             // 1: rows leave as 16-byte vector stores when the step's block is 16-byte aligned
+#endif
 #ifndef R512F_MINWAVES_F32
 #define R512F_MINWAVES_F32 2
 #endif
@@ -111,14 +117,15 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
     T2 *ttab = reinterpret_cast<T2 *>(wtab + 512);                     // W256^(j k1) at [k1][j], 256 T2
 
     // ---- per-lane constants ----
-    T twr[16], twi[16];                                    // W256^(j k1) = W512^(2 j k1)
+    using C = cx<T>;
+    C twd[16];                                             // W256^(j k1) = W512^(2 j k1)
     if (TWREG) {
 #pragma unroll
         for (int k1 = 1; k1 < 16; ++k1) {
             int idx = 2 * j * k1;
             T sg = T(1);
             if (idx >= 256) { idx -= 256; sg = T(-1); }
-            twr[k1] = sg * tw[2 * idx]; twi[k1] = sg * tw[2 * idx + 1];
+            twd[k1] = C{sg * tw[2 * idx], sg * tw[2 * idx + 1]};
         }
     } else {
         const int k1 = tid >> 4, jj = tid & 15;
@@ -128,16 +135,15 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
         T2 t; t.x = sg * tw[2 * idx]; t.y = sg * tw[2 * idx + 1];
         ttab[tid] = t;
     }
-    T owr[8], owi[8];                                      // W512^(j + 16 k2), k2 < 8
+    C ow[8];                                               // -i W512^(j + 16 k2), k2 < 8
 #pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) { owr[k2] = tw[2 * (j + 16 * k2)]; owi[k2] = tw[2 * (j + 16 * k2) + 1]; }
-    T hw0[NR], hw1[NR];                                    // halved window taps of this lane's columns
+    for (int k2 = 0; k2 < 8; ++k2) { ow[k2] = C{tw[2 * (j + 16 * k2) + 1], -tw[2 * (j + 16 * k2)]}; }
+    C hw[NR];                                              // halved window taps of this lane's columns
     if (WINREG) {
 #pragma unroll
         for (int n1 = 0; n1 < NR; ++n1) {
             const int l = 32 * n1 + 2 * j;
-            hw0[n1] = (l < L) ? T(0.5) * win[l] : T(0);
-            hw1[n1] = (l + 1 < L) ? T(0.5) * win[l + 1] : T(0);
+            hw[n1] = C{(l < L) ? T(0.5) * win[l] : T(0), (l + 1 < L) ? T(0.5) * win[l + 1] : T(0)};
         }
     } else {
         for (int l = tid; l < 512; l += 256) { wtab[l] = (l < L) ? T(0.5) * win[l] : T(0); }
@@ -226,42 +232,52 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
     // outstanding instead of draining the store queue.
     while (true) {
         // ---- pass 1: lane (frame f, column n2 = j): 16-point FFT over the rows n1 ----
-        T re[16], im[16];
+        C zz[16];
+#if R512F_OPAQUE_TW
+        if constexpr (sizeof(T) == 4) {
+            // the twiddles look freshly written each step, so their sign-flipped copies are not kept
+            // in registers across the loop (one waves-per-SIMD step of occupancy)
+#pragma unroll
+            for (int k1 = 1; k1 < 16; ++k1) { asm volatile("" : "+v"(twd[k1])); }
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) { asm volatile("" : "+v"(ow[k2])); }
+        }
+#endif
 #if R512F_ABLATE != 1
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
             if (n1 < NR) {
                 const T2 t = *reinterpret_cast<const T2 *>(xrow + 32 * n1);
-                T p = t.x, c = t.y;
+                C v = C{t.x, t.y};
                 if (NR == 16 || n1 == NR - 1) {          // rows that may reach past the window
                     const int l = 32 * n1 + 2 * j;
-                    p = (l < L) ? p : T(0);
-                    c = (l + 1 < L) ? c : T(0);
+                    v.x = (l < L) ? v.x : T(0);
+                    v.y = (l + 1 < L) ? v.y : T(0);
                 }
-                T h0, h1;
-                if (WINREG) { h0 = hw0[n1]; h1 = hw1[n1]; }
-                else { const T2 h = *reinterpret_cast<const T2 *>(wtab + 32 * n1 + 2 * j); h0 = h.x; h1 = h.y; }
-                re[n1] = p * h0; im[n1] = c * h1;
+                C h;
+                if (WINREG) { h = hw[n1]; }
+                else { const T2 hh = *reinterpret_cast<const T2 *>(wtab + 32 * n1 + 2 * j); h = C{hh.x, hh.y}; }
+                zz[n1] = v * h;
             } else {
-                re[n1] = T(0); im[n1] = T(0);
+                zz[n1] = C{T(0), T(0)};
             }
         }
         if (MN0) {
-            T sum = T(0);
+            C acc = zz[0];
 #pragma unroll
-            for (int n1 = 0; n1 < NR; ++n1) { sum += re[n1] + im[n1]; }
+            for (int n1 = 1; n1 < NR; ++n1) { acc += zz[n1]; }
+            T sum = acc.x + acc.y;
             sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2);
             sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8);
             const T mean = sum / T(L);
 #pragma unroll
             for (int n1 = 0; n1 < NR; ++n1) {
                 const int l = 32 * n1 + 2 * j;
-                re[n1] -= (l < L) ? mean : T(0);
-                im[n1] -= (l + 1 < L) ? mean : T(0);
+                zz[n1] -= C{(l < L) ? mean : T(0), (l + 1 < L) ? mean : T(0)};
             }
         }
 #if R512F_ABLATE != 3
-        dft16<T, NR>(re, im);
+        dft16c<T, NR>(zz);
 #endif
         R512F_STAMP(0);
         wave_sync();                                       // all lanes have read the span: the tile may overwrite it
@@ -270,12 +286,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
             T2 *exf = ex + f * R512_EXF + j;
 #pragma unroll
             for (int k1 = 0; k1 < 16; ++k1) {
-                T r = re[slot16(k1)], i = im[slot16(k1)];
+                C v = zz[slot16(k1)];
                 if (k1 > 0) {
-                    if (TWREG) { cmul(r, i, twr[k1], twi[k1]); }
-                    else { const T2 t = ttab[k1 * 16 + j]; cmul(r, i, t.x, t.y); }
+                    if (TWREG) { v = cx_mul<T>(v, twd[k1]); }
+                    else { const T2 t = ttab[k1 * 16 + j]; v = cx_mul<T>(v, t.x, t.y); }
                 }
-                T2 o; o.x = r; o.y = i;
+                T2 o; o.x = v.x; o.y = v.y;
                 exf[k1 * 17] = o;
             }
         }
@@ -286,14 +302,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
         {
             const T2 *exf = ex + f * R512_EXF + j * 17;
 #pragma unroll
-            for (int n2 = 0; n2 < 16; ++n2) { const T2 t = exf[n2]; re[n2] = t.x; im[n2] = t.y; }
+            for (int n2 = 0; n2 < 16; ++n2) { const T2 t = exf[n2]; zz[n2] = C{t.x, t.y}; }
         }
 #else
 #pragma unroll
-        for (int k1 = 1; k1 < 16; ++k1) { cmul(re[k1], im[k1], twr[k1], twi[k1]); }
+        for (int k1 = 1; k1 < 16; ++k1) { zz[k1] = cx_mul<T>(zz[k1], twd[k1]); }
 #endif
 #if R512F_ABLATE != 3
-        dft16<T, 16>(re, im);
+        dft16c<T, 16>(zz);
 #endif
         R512F_STAMP(2);
 
@@ -303,24 +319,22 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
         // With A = Z_k + conj Z_{256-k}, B = Z_k - conj Z_{256-k}, T = -i W512^k B:
         // |X_k|^2 = |A + T|^2 and |X_{256-k}|^2 = |A - T|^2.
         T pw[16];                                          // pw[k2] = P[k], pw[8 + k2] = P[256 - k]
-        T p128 = T(4) * (re[slot16(8)] * re[slot16(8)] + im[slot16(8)] * im[slot16(8)]);   // lane j == 0 only
+        T p128 = T(4) * cx_norm<T>(zz[slot16(8)]);         // lane j == 0 only
 #pragma unroll
         for (int k2 = 0; k2 < 8; ++k2) {
-            const T zx = re[slot16(k2)], zy = im[slot16(k2)];
+            const C z = zz[slot16(k2)];
             // (the empty asm keeps the compiler from turning the select of two array elements into a
             // select of the index, which it would lower to a 16-way chain of conditional moves)
-            T x0 = re[slot16((16 - k2) & 15)], x1 = re[slot16(15 - k2)];
-            T y0 = im[slot16((16 - k2) & 15)], y1 = im[slot16(15 - k2)];
+            T x0 = zz[slot16((16 - k2) & 15)].x, x1 = zz[slot16(15 - k2)].x;
+            T y0 = zz[slot16((16 - k2) & 15)].y, y1 = zz[slot16(15 - k2)].y;
             asm volatile("" : "+v"(x0), "+v"(x1), "+v"(y0), "+v"(y1));
             const T sx = (j == 0) ? x0 : x1;
             const T sy = (j == 0) ? y0 : y1;
-            const T mx = dpp_partner16(sx), my = dpp_partner16(sy);
-            const T ar = zx + mx, ai = zy - my, br = zx - mx, bi = zy + my;
-            const T wr = owr[k2], wi = owi[k2];
-            const T tr = br * wi + bi * wr, ti = bi * wi - br * wr;
-            const T pr = ar + tr, pi = ai + ti, qr = ar - tr, qi = ai - ti;
-            pw[k2] = pr * pr + pi * pi;
-            pw[8 + k2] = qr * qr + qi * qi;
+            const C m = C{dpp_partner16(sx), dpp_partner16(sy)};
+            const C A = cx_add_conj<T>(z, m), B = cx_sub_conj<T>(z, m);
+            const C Tw = cx_mul<T>(B, ow[k2]);
+            pw[k2] = cx_norm<T>(A + Tw);
+            pw[8 + k2] = cx_norm<T>(A - Tw);
         }
         if (EPI) {
 #pragma unroll
@@ -346,6 +360,17 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
         // of store instructions per step stays fixed)
         {
             T *yblk = yb + (unsigned)(w * F);
+#if R512F_ST4
+            if (a.W - w >= 4 && (reinterpret_cast<uintptr_t>(yblk) & 15) == 0) {
+                // 1028 values = 257 16-byte vectors (float) / 514 (double): whole-vector wave stores
+                constexpr int NVEC = 1028 / VEC, FULLI = NVEC / 64;
+#pragma unroll
+                for (int i = 0; i <= FULLI; ++i) {
+                    const int idx = (i < FULLI) ? lane + 64 * i : FULLI * 64 + (lane & (NVEC - FULLI * 64 - 1));
+                    reinterpret_cast<TV *>(yblk)[idx] = reinterpret_cast<const TV *>(xs)[idx];
+                }
+            } else
+#endif
             if (a.W - w >= 4) {
 #pragma unroll
                 for (int i = 0; i < 17; ++i) {

@@ -41,6 +41,7 @@ constexpr int R4096_WAVE_C = 64 * R4096_PITCH;          // complex slots per wav
 constexpr int R4096_WAVES = 8;                          // waves per workgroup (share the window table)
 typedef float2 __attribute__((aligned(4))) float2_u;    // frame starts are only 4-byte aligned
 typedef unsigned u2v __attribute__((ext_vector_type(2)));
+typedef float4 __attribute__((aligned(4))) float4_u;
 
 #ifndef R4096_ABLATE
 #define R4096_ABLATE 0          // diagnostic builds: bit 0 = no row stores, bit 1 = no sample loads
@@ -105,7 +106,13 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
 
     for (int l = tid; l < 4096; l += 64 * R4096_WAVES) { wtab[l] = (l < L) ? 0.5f * win[l] : 0.0f; }
 
-    // per-lane twiddles: W2048^(lane b), b = 1..3, and W2048^(4 lane a), a = 1..7
+    // Lane roles.  Loads: half-wave u takes the rows n1 = 2 i + u, lane l4 of it the complex columns
+    // 2 l4 and 2 l4 + 1 (one 16-byte load per row).  After the 16-point transforms one swap between the
+    // half-waves leaves every lane with both halves of ONE column, n2 = 2 l4 + u.
+    const int l4 = lane & 31, up = lane >> 5;
+    const int n2 = 2 * l4 + up;
+    const int hi16 = (lane >> 4) & 1, j16 = lane & 15;         // n2 = 32 hi16 + 2 j16 + up
+    // per-lane twiddles: W2048^(n2 b), b = 1..3, and W2048^(4 n2 a), a = 1..7
     auto tw2048 = [&](int m) {                            // W2048^m = W4096^(2m), table holds k < 2048
         int idx = (2 * m) & 4095;
         float sg = 1.0f;
@@ -114,12 +121,13 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
     };
     C2 tb[4], ta[8];
 #pragma unroll
-    for (int b = 1; b < 4; ++b) { tb[b] = tw2048(lane * b); }
+    for (int b = 1; b < 4; ++b) { tb[b] = tw2048(n2 * b); }
 #pragma unroll
-    for (int q = 1; q < 8; ++q) { ta[q] = tw2048(4 * lane * q); }
-    const int n2h = lane & 31, up = lane >> 5;
-    const C2 wl = C2{tw[2 * 64 * n2h], tw[2 * 64 * n2h + 1]};          // W64^(lane % 32)
-    const C2 owm = C2{tw[2 * lane + 1], -tw[2 * lane]};                // -i W4096^lane, for the split
+    for (int q = 1; q < 8; ++q) { ta[q] = tw2048(4 * n2 * q); }
+    const C2 wl = C2{tw[2 * 64 * (n2 & 31)], tw[2 * 64 * (n2 & 31) + 1]};   // W64^(n2 % 32)
+    C2 owm[4];                                                            // -i W4096^(4 lane + c), for the split
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { owm[c] = C2{tw[2 * (4 * lane + c) + 1], -tw[2 * (4 * lane + c)]}; }
     __syncthreads();
 
     // frames: 8 contiguous ranges by blockIdx % 8, round-robin over the waves inside a range
@@ -143,18 +151,19 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         q.inside = q.ss >= 0 && q.ss + 4096 <= a.N && q.ss >= q.rdoff;
         return q;
     };
-    C2 ze[16], zo[16];                              // even / odd rows of the 32-point transforms
-    // raw samples of a frame that lies inside its signal: 32 coalesced 512-byte wave loads
+    C2 ze[16], zo[16];      // loads: columns 2 l4 (ze) and 2 l4 + 1 (zo), rows 2 i + up; later: the two halves of a 32-point transform
+    const int loff = 128 * up + 4 * l4;                     // first sample of the lane inside a frame; row i adds 256
+    // raw samples of a frame that lies inside its signal: 16 coalesced 1-KiB wave loads
     auto load_inside = [&](const Where &q) {
-        const float *src = q.xb + (q.ss - q.rdoff) + 2 * lane;
+        const float *src = q.xb + (q.ss - q.rdoff) + loff;
 #pragma unroll
-        for (int n1 = 0; n1 < 32; ++n1) {
-            float2 v = make_float2(0.f, 0.f);
+        for (int i = 0; i < 16; ++i) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
 #if R4096_ABLATE & 2
             if (a.N == -12345)
 #endif
-            if (FULL || 128 * n1 < L) { v = *reinterpret_cast<const float2_u *>(src + 128 * n1); }
-            if (n1 & 1) { zo[n1 >> 1] = C2{v.x, v.y}; } else { ze[n1 >> 1] = C2{v.x, v.y}; }
+            if (FULL || 256 * i < L) { v = *reinterpret_cast<const float4_u *>(src + 256 * i); }
+            ze[i] = C2{v.x, v.y}; zo[i] = C2{v.z, v.w};
         }
     };
     // a frame that crosses an edge of its signal: gather sample by sample into the (idle) tile first
@@ -166,9 +175,9 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         for (int l = lane; l < 4096; l += 64) { stage[l] = (l < L) ? fetch_sample(q.xb, d, q.ss, q.rdoff, l) : 0.f; }
         wave_sync();
 #pragma unroll
-        for (int n1 = 0; n1 < 32; ++n1) {
-            const float2 v = *reinterpret_cast<const float2 *>(stage + 128 * n1 + 2 * lane);
-            if (n1 & 1) { zo[n1 >> 1] = C2{v.x, v.y}; } else { ze[n1 >> 1] = C2{v.x, v.y}; }
+        for (int i = 0; i < 16; ++i) {
+            const float4 v = *reinterpret_cast<const float4 *>(stage + loff + 256 * i);
+            ze[i] = C2{v.x, v.y}; zo[i] = C2{v.z, v.w};
         }
         asm volatile("" ::: "memory");                 // keeps these LDS reads from being merged with load_inside's into flat loads
     };
@@ -188,18 +197,20 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         // ---------------- pass 1: window, 32-point FFT over n1 ----------------
         {
             C2 acc = C2{0.f, 0.f};
-            int lim = L - 2 * lane;                          // sample l = 128 n1 + 2 lane is inside the window iff 128 n1 < lim
-            asm volatile("" : "+v"(lim));                    // recomputed per frame: 64 hoisted lane masks would not fit in SGPRs
+            int lim = L - loff;                              // sample l = 256 i + loff + c is inside the window iff 256 i + c < lim
+            asm volatile("" : "+v"(lim));                    // recomputed per frame: hoisted lane masks would not fit in SGPRs
 #pragma unroll
-            for (int n1 = 0; n1 < 32; ++n1) {
-                const float2 hh = *reinterpret_cast<const float2 *>(wtab + 128 * n1 + 2 * lane);
-                C2 &z = (n1 & 1) ? zo[n1 >> 1] : ze[n1 >> 1];
+            for (int i = 0; i < 16; ++i) {
+                const float4 hh = *reinterpret_cast<const float4 *>(wtab + loff + 256 * i);
                 if (!FULL) {                                 // keep data past the window out (0 * NaN)
-                    z.x = (128 * n1 < lim) ? z.x : 0.f;
-                    z.y = (128 * n1 + 1 < lim) ? z.y : 0.f;
+                    ze[i].x = (256 * i < lim) ? ze[i].x : 0.f;
+                    ze[i].y = (256 * i + 1 < lim) ? ze[i].y : 0.f;
+                    zo[i].x = (256 * i + 2 < lim) ? zo[i].x : 0.f;
+                    zo[i].y = (256 * i + 3 < lim) ? zo[i].y : 0.f;
                 }
-                z = z * C2{hh.x, hh.y};
-                if (MN0) { acc += z; }
+                ze[i] = ze[i] * C2{hh.x, hh.y};
+                zo[i] = zo[i] * C2{hh.z, hh.w};
+                if (MN0) { acc += ze[i] + zo[i]; }
             }
             if (MN0) {
                 float sum = acc.x + acc.y;
@@ -207,16 +218,32 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
                 for (int o = 1; o < 64; o <<= 1) { sum += __shfl_xor(sum, o); }
                 const float mean = sum / (float)L;
 #pragma unroll
-                for (int n1 = 0; n1 < 32; ++n1) {
-                    C2 &z = (n1 & 1) ? zo[n1 >> 1] : ze[n1 >> 1];
-                    z -= C2{(FULL || 128 * n1 < lim) ? mean : 0.f, (FULL || 128 * n1 + 1 < lim) ? mean : 0.f};
+                for (int i = 0; i < 16; ++i) {
+                    ze[i] -= C2{(FULL || 256 * i < lim) ? mean : 0.f, (FULL || 256 * i + 1 < lim) ? mean : 0.f};
+                    zo[i] -= C2{(FULL || 256 * i + 2 < lim) ? mean : 0.f, (FULL || 256 * i + 3 < lim) ? mean : 0.f};
                 }
             }
         }
-        dft32c(ze, zo);
+        // 16-point transforms over this half-wave's rows, for both columns; then the half-waves trade
+        // one column each, so that a lane holds E (even rows) and O (odd rows) of column n2, and
+        // X[k1] = E + W32^k1 O, X[k1 + 16] = E - W32^k1 O
+        dft16c<float, 16>(ze);
+        dft16c<float, 16>(zo);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int s = slot16(k);
+            const u2v sr = __builtin_amdgcn_permlane32_swap(__float_as_uint(ze[s].x), __float_as_uint(zo[s].x), false, false);
+            const u2v si = __builtin_amdgcn_permlane32_swap(__float_as_uint(ze[s].y), __float_as_uint(zo[s].y), false, false);
+            const C2 E = C2{__uint_as_float(sr.x), __uint_as_float(si.x)};
+            C2 t = C2{__uint_as_float(sr.y), __uint_as_float(si.y)};
+            if (k == 8) { t = cx_swap(t) * C2{1.f, -1.f}; }
+            else if (k > 0) { t = cx_mul<float>(t, W32C[2 * k], W32C[2 * k + 1]); }
+            ze[s] = E + t;
+            zo[s] = E - t;
+        }
         R4096_STAMP(0);
 
-        // twiddle W2048^(lane k1), k1 = 4 q + b
+        // twiddle W2048^(n2 k1), k1 = 4 q + b
 #pragma unroll
         for (int k1 = 1; k1 < 32; ++k1) {
             C2 &z = (k1 < 16) ? ze[slot16(k1)] : zo[slot16(k1 - 16)];
@@ -224,17 +251,18 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
             if (bb) { z = cx_mul<float>(z, tb[bb]); }
             if (q) { z = cx_mul<float>(z, ta[q]); }
         }
-        // first radix-2 stage of the 64-point transforms over n2, rows k1 and k1 + 16 in one swap:
-        // afterwards the lower half-wave holds row k1 (x = column n2, y = column n2 + 32), the upper
-        // half-wave row k1 + 16
+        // first radix-2 stage of the 64-point transforms over n2: columns n2 and n2 + 32 sit 16 lanes
+        // apart; one swap of rows k1 and k1 + 16 leaves the even 16-lane groups with row k1
+        // (x = column n2, y = column n2 + 32) and the odd groups with row k1 + 16
         wave_sync();                                       // the previous frame's reads of the tile are done
         {
-            C2 *dst = ex + (32 * up) * R4096_PITCH + n2h;  // rows 2 k1 + parity, k1 = a + 16 up
+            // tile row 2 k1 + parity; column n2 % 32 = 2 j16 + up is kept at position j16 + 16 up
+            C2 *dst = ex + (32 * hi16) * R4096_PITCH + j16 + 16 * up;
 #pragma unroll
             for (int k1 = 0; k1 < 16; ++k1) {
                 const C2 lo = ze[slot16(k1)], hi = zo[slot16(k1)];
-                const u2v sr = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo.x), __float_as_uint(hi.x), false, false);
-                const u2v si = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo.y), __float_as_uint(hi.y), false, false);
+                const u2v sr = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo.x), __float_as_uint(hi.x), false, false);
+                const u2v si = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo.y), __float_as_uint(hi.y), false, false);
                 const C2 x = C2{__uint_as_float(sr.x), __uint_as_float(si.x)};
                 const C2 y = C2{__uint_as_float(sr.y), __uint_as_float(si.y)};
                 dst[(2 * k1) * R4096_PITCH] = x + y;
@@ -248,9 +276,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         {
             const C2 *row = ex + lane * R4096_PITCH;
 #pragma unroll
-            for (int m = 0; m < 32; ++m) {
-                if (m & 1) { zo[m >> 1] = row[m]; } else { ze[m >> 1] = row[m]; }
-            }
+            for (int m = 0; m < 16; ++m) { ze[m] = row[m]; zo[m] = row[16 + m]; }   // even / odd columns
         }
         dft32c(ze, zo);
         R4096_STAMP(2);
@@ -272,27 +298,36 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         if (nxt.inside) { load_inside(nxt); }
         R4096_STAMP(4);
 
-        // ---------------- split + power + store: lane handles bins k = lane + 64 m and 2048 - k ----------------
+        // ---------------- split + power + store: lane handles bins k = 4 lane + c + 256 m and 2048 - k ----------------
         float *y = Y + cur.row * F;
-        const C2 *zk = ex + zpos(lane);
-        const C2 *zmk = ex + (lane == 0 ? 64 * 17 : zpos(M - lane) - 64 * 15);     // Z[2048 - lane - 64 m] at zmk[64 (15 - m)]
+        const C2 *zk = ex + zpos(4 * lane);                                // Z[k] at zk[256 m + c]
+        const C2 *zq0 = ex + zpos(M - 4 * lane) - 768;                     // Z[2048 - 4 lane - 256 m] at zq0[256 (3 - m)]
+        const C2 *zq4 = ex + zpos(M - 4 - 4 * lane) - 768;                 // Z[2048 - 4 lane - 256 m - 4 + i] at zq4[256 (3 - m) + i]
 #pragma unroll
-        for (int m = 0; m < 16; ++m) {
-            const int k = lane + 64 * m;
-            const C2 z = zk[64 * m];
-            const C2 zm = (m == 0) ? ((lane == 0) ? z : zmk[64 * 15]) : zmk[64 * (15 - m)];
-            const C2 A = cx_add_conj<float>(z, zm);
-            C2 B = cx_sub_conj<float>(z, zm);
-            // -i W4096^k B with W4096^k = W4096^lane W64^m
-            if (m > 0) { B = cx_mul<float>(B, W64C[2 * m], W64C[2 * m + 1]); }
-            const C2 Tw = cx_mul<float>(B, owm);
-            float p = cx_norm<float>(A + Tw), q = cx_norm<float>(A - Tw);
-            if (EPI) { p = power_epilogue(p, a.amp, a.lg); q = power_epilogue(q, a.amp, a.lg); }
+        for (int m = 0; m < 4; ++m) {
+            float p[4], q[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const C2 z = zk[256 * m + c];
+                C2 zm = (c == 0) ? zq0[256 * (3 - m)] : zq4[256 * (3 - m) + 4 - c];
+                if (m == 0 && c == 0) { zm = (lane == 0) ? z : zm; }         // bin 0 pairs with itself
+                const C2 A = cx_add_conj<float>(z, zm);
+                C2 B = cx_sub_conj<float>(z, zm);
+                // -i W4096^k B with W4096^k = W4096^(4 lane + c) W16^m
+                if (m > 0) { B = cx_mul<float>(B, W64C[8 * m], W64C[8 * m + 1]); }
+                const C2 Tw = cx_mul<float>(B, owm[c]);
+                p[c] = cx_norm<float>(A + Tw); q[c] = cx_norm<float>(A - Tw);
+                if (EPI) { p[c] = power_epilogue(p[c], a.amp, a.lg); q[c] = power_epilogue(q[c], a.amp, a.lg); }
+            }
+            const int k0 = 4 * lane + 256 * m;
 #if R4096_ABLATE & 1
-            asm volatile("" :: "v"(p), "v"(q));
+            asm volatile("" :: "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]));
             if (a.N == -12345)
 #endif
-            { y[k] = p; y[M - k] = q; }
+            {
+                *reinterpret_cast<float4_u *>(y + k0) = make_float4(p[0], p[1], p[2], p[3]);
+                *reinterpret_cast<float4_u *>(y + M - 3 - k0) = make_float4(q[3], q[2], q[1], q[0]);
+            }
         }
         if (lane == 0) {
             float p = 4.0f * cx_norm<float>(ex[1024]);     // bin 1024 pairs with itself (Z holds half values)

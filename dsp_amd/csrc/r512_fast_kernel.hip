@@ -87,8 +87,11 @@ __device__ unsigned long long g_r512f_stamps[8192 * 8];
 #ifndef R512F_OPAQUE_TW
 #define R512F_OPAQUE_TW 0
 #endif
+#ifndef R512F_TW_LDS_F64
+#define R512F_TW_LDS_F64 1      // 1: the double kernel reads its pass-1 twiddles from LDS (they do not fit in registers)
+#endif
 #ifndef R512F_ST4
-#define R512F_ST4 0             // 1: rows leave as 16-byte vector stores when the step's block is 16-byte aligned
+#define R512F_ST4 1             // 1: rows leave as 16-byte vector stores when the step's block is 16-byte aligned
 #endif
 #ifndef R512F_MINWAVES_F32
 #define R512F_MINWAVES_F32 2
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
     using TV = typename vec16<T>::type;
     constexpr int VEC = vec16<T>::n, NV = 16 / VEC;        // 16 staged elements per lane
     constexpr bool WINREG = (sizeof(T) == 4) && !R512F_WIN_LDS;
-    constexpr bool TWREG = !R512F_TW_LDS;
+    constexpr bool TWREG = !R512F_TW_LDS && !(R512F_TW_LDS_F64 && sizeof(T) == 8);
     constexpr int M = 256, F = 257;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;

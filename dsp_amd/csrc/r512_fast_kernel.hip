@@ -55,7 +55,7 @@ template <> struct vec16<double> { using type = double2; static constexpr int n 
 #define R512F_WIN_LDS 0         // 1: float window taps come from LDS too (double always does)
 #endif
 #ifndef R512F_ABLATE
-#define R512F_ABLATE 0          // diagnostic builds: 1 = memory traffic only, 2 = no stores, 3 = no LDS output stage
+#define R512F_ABLATE 0          // diagnostic builds: 1 = memory traffic only, 2 = no scalar-path stores, 3 = no FFT arithmetic, 4 = no exchange through LDS
 #endif
 #ifndef R512F_NT_STORE
 #define R512F_NT_STORE 0        // 1: spectrogram rows are stored with the non-temporal hint
@@ -84,11 +84,14 @@ __device__ unsigned long long g_r512f_stamps[8192 * 8];
 #else
 #define R512F_STAMP(i) do {} while (0)
 #endif
-#ifndef R512F_OPAQUE_TW
-#define R512F_OPAQUE_TW 0
-#endif
 #ifndef R512F_TW_LDS_F64
 #define R512F_TW_LDS_F64 1      // 1: the double kernel reads its pass-1 twiddles from LDS (they do not fit in registers)
+#endif
+#ifndef R512F_NOLOAD
+#define R512F_NOLOAD 0          // diagnostic builds: 1 = the span loads are compiled out
+#endif
+#ifndef R512F_NOSTORE
+#define R512F_NOSTORE 0         // diagnostic builds: 1 = the row stores are compiled out
 #endif
 #ifndef R512F_ST4
 #define R512F_ST4 1             // 1: rows leave as 16-byte vector stores when the step's block is 16-byte aligned
@@ -167,6 +170,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
             for (int q = 0; q < NV; ++q) {
                 // only 3*hop + 32*NR samples are ever read by pass 1: lanes past that re-read the last
                 // needed vector (same cache line, no extra traffic) so that the number of loads stays fixed
+#if R512F_NOLOAD
+                if (a.N == -12345)
+#endif
                 pre[q] = reinterpret_cast<const TV *>(src)[min(q * 64 + lane, nvec - 1)];
             }
         } else {
@@ -236,16 +242,6 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
     while (true) {
         // ---- pass 1: lane (frame f, column n2 = j): 16-point FFT over the rows n1 ----
         C zz[16];
-#if R512F_OPAQUE_TW
-        if constexpr (sizeof(T) == 4) {
-            // the twiddles look freshly written each step, so their sign-flipped copies are not kept
-            // in registers across the loop (one waves-per-SIMD step of occupancy)
-#pragma unroll
-            for (int k1 = 1; k1 < 16; ++k1) { asm volatile("" : "+v"(twd[k1])); }
-#pragma unroll
-            for (int k2 = 0; k2 < 8; ++k2) { asm volatile("" : "+v"(ow[k2])); }
-        }
-#endif
 #if R512F_ABLATE != 1
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
@@ -370,7 +366,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
 #pragma unroll
                 for (int i = 0; i <= FULLI; ++i) {
                     const int idx = (i < FULLI) ? lane + 64 * i : FULLI * 64 + (lane & (NVEC - FULLI * 64 - 1));
+#if R512F_NOSTORE
+                    const TV v4 = reinterpret_cast<const TV *>(xs)[idx];
+                    asm volatile("" :: "v"(v4.x), "v"(v4.y));
+                    if (a.N == -12345) { reinterpret_cast<TV *>(yblk)[idx] = v4; }
+#else
                     reinterpret_cast<TV *>(yblk)[idx] = reinterpret_cast<const TV *>(xs)[idx];
+#endif
                 }
             } else
 #endif
@@ -445,7 +447,7 @@ static hipError_t launch_fast_inst(T *Y, const T *X, const T *win, const T *tw, 
         if (e != hipSuccess) { return e; }
         granted = lds;
     }
-    static const int wgs_per_cu = [] { const char *e = getenv("DSP_R512F_WGS_PER_CU"); return e ? atoi(e) : 4; }();
+    static const int wgs_per_cu = [] { const char *e = getenv("DSP_R512F_WGS_PER_CU"); return e ? atoi(e) : 2; }();
     long long grid = ((long long)a.steps + 3) / 4;
     if (grid > 256ll * wgs_per_cu) { grid = 256ll * wgs_per_cu; }
     grid = (grid + 7) & ~7ll;                           // whole groups of 8 workgroups (one per XCD)

@@ -41,6 +41,12 @@ SIGNATURES = {
     "dsp_stft_flt_batch_dev_d": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _d, _d, _int, _int, _int, _vp]),
     "dsp_stft_batch_s": (_int, _BHOST), "dsp_stft_batch_d": (_int, _BHOST),
     "dsp_fft_power_dev_c": (_int, [_vp, _vp, _sz, _vp]), "dsp_fft_power_dev_z": (_int, [_vp, _vp, _sz, _vp]),
+    "pow_compress_s": (_int, [_vp, _vp, _sz, _f, _f]), "pow_compress_d": (_int, [_vp, _vp, _sz, _d, _d]),
+    "pow_compress_inplace_s": (_int, [_vp, _sz, _f, _f]), "pow_compress_inplace_d": (_int, [_vp, _sz, _d, _d]),
+    "get_stft_freqs_s": (_int, [_vp, _sz, _sz, _f]), "get_stft_freqs_d": (_int, [_vp, _sz, _sz, _d]),
+    "dsp_pow_compress_dev_s": (_int, [_vp, _vp, _sz, _f, _f, _vp]), "dsp_pow_compress_dev_d": (_int, [_vp, _vp, _sz, _d, _d, _vp]),
+    "dsp_stft_pc_batch_dev_s": (_int, _BDEV[:-1] + [_f, _f, _vp]), "dsp_stft_pc_batch_dev_d": (_int, _BDEV[:-1] + [_d, _d, _vp]),
+    "dsp_stft_pc_batch_s": (_int, _BHOST + [_f, _f]), "dsp_stft_pc_batch_d": (_int, _BHOST + [_d, _d]),
     "dsp_stft_kernel_family": (_int, [_sz, _sz]),
     "dsp_stft_force_generic": (_int, [_int]),
     "dsp_stft_version": (C.c_char_p, []),

@@ -189,6 +189,50 @@ def fft_power(xc):
     return Y
 
 
+def pow_compress(x, p, preg=0.0, inplace=False):
+    """pow_compress_s / _d (and _inplace_): f(x + preg) element-wise, f chosen by the exponent p in [0, 1]."""
+    x = np.ascontiguousarray(x)
+    s = _real_sfx(x.dtype)
+    if inplace:
+        rc = getattr(lib(), f"pow_compress_inplace_{s}")(_p(x), x.size, float(p), float(preg))
+        _check(rc, f"pow_compress_inplace_{s}")
+        return x
+    Y = np.empty_like(x)
+    rc = getattr(lib(), f"pow_compress_{s}")(_p(Y), _p(x), x.size, float(p), float(preg))
+    _check(rc, f"pow_compress_{s}")
+    return Y
+
+
+def get_stft_freqs(nfft, F, fs, dtype=np.float32):
+    """get_stft_freqs_s / _d: the first F bin frequencies of an nfft-point STFT at sample rate fs."""
+    s = _real_sfx(np.dtype(dtype))
+    Y = np.empty(F, dtype=dtype)
+    rc = getattr(lib(), f"get_stft_freqs_{s}")(_p(Y), nfft, F, float(fs))
+    _check(rc, f"get_stft_freqs_{s}")
+    return Y
+
+
+def stft_pc_batch(x, win, p, preg=0.0, stp=160, snip_edges=False, mn0=False, amp=False, lg=False, nfft=None):
+    """dsp_stft_pc_batch_s / _d: stft_batch with pow_compress(., p, preg) fused into the store.  x: [B, N]."""
+    x = np.asarray(x)
+    if x.ndim == 1:
+        x = x[None, :]
+    if x.ndim != 2 or x.strides[1] != x.itemsize or (x.shape[0] > 1 and x.strides[0] % x.itemsize):
+        x = np.ascontiguousarray(x)
+    s = _real_sfx(x.dtype)
+    win = np.ascontiguousarray(win, dtype=x.dtype)
+    B, N = x.shape
+    ldx = x.strides[0] // x.itemsize if B > 1 else N
+    L = win.size
+    nfft = nextpow2(L) if nfft is None else int(nfft)
+    W = num_frames(N, L, stp, snip_edges)
+    Y = np.empty((B, W, nfft // 2 + 1), dtype=x.dtype)
+    rc = getattr(lib(), f"dsp_stft_pc_batch_{s}")(_p(Y), _p(x), _p(win), B, N, ldx, L, nfft, stp, int(bool(snip_edges)),
+                                                  int(bool(mn0)), int(bool(amp)), int(bool(lg)), float(p), float(preg))
+    _check(rc, f"dsp_stft_pc_batch_{s}")
+    return Y
+
+
 # ------------------------------------------------------------------------------------------------
 # device-resident forms (torch tensors are only the carrier of device memory and of the stream)
 # ------------------------------------------------------------------------------------------------
@@ -231,6 +275,48 @@ def stft_dev(x, win, stp=160, snip_edges=False, mn0=False, amp=False, lg=False, 
                                                        int(bool(snip_edges)), int(bool(mn0)), int(bool(amp)),
                                                        int(bool(lg)), _stream_ptr(x))
     _check(rc, f"dsp_stft_batch_dev_{s}")
+    return out
+
+
+def stft_pc_dev(x, win, p, preg=0.0, stp=160, snip_edges=False, mn0=False, amp=False, lg=False, nfft=None, out=None):
+    """dsp_stft_pc_batch_dev_s / _d: stft_dev with pow_compress(., p, preg) fused into the store."""
+    import torch
+    if x.dim() == 1:
+        x = x.unsqueeze(0)
+    if not x.is_cuda or x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("x must be a device tensor [B, N] with unit stride along N")
+    s = _torch_sfx(x)
+    win = win.to(device=x.device, dtype=x.dtype).contiguous()
+    B, N = x.shape
+    ldx = x.stride(0) if B > 1 else N
+    L = win.numel()
+    nfft = nextpow2(L) if nfft is None else int(nfft)
+    W = num_frames(N, L, stp, snip_edges)
+    if out is None:
+        out = torch.empty((B, W, nfft // 2 + 1), dtype=x.dtype, device=x.device)
+    elif tuple(out.shape) != (B, W, nfft // 2 + 1) or not out.is_contiguous() or out.dtype != x.dtype:
+        raise ValueError("out must be a contiguous [B, W, F] tensor of x's dtype")
+    with torch.cuda.device(x.device):
+        rc = getattr(lib(), f"dsp_stft_pc_batch_dev_{s}")(C.c_void_p(out.data_ptr()), C.c_void_p(x.data_ptr()),
+                                                          C.c_void_p(win.data_ptr()), B, N, ldx, L, nfft, stp,
+                                                          int(bool(snip_edges)), int(bool(mn0)), int(bool(amp)),
+                                                          int(bool(lg)), float(p), float(preg), _stream_ptr(x))
+    _check(rc, f"dsp_stft_pc_batch_dev_{s}")
+    return out
+
+
+def pow_compress_dev(x, p, preg=0.0, out=None):
+    """dsp_pow_compress_dev_s / _d over a contiguous device tensor (out may be x)."""
+    import torch
+    if not x.is_cuda or not x.is_contiguous():
+        raise ValueError("x must be a contiguous device tensor")
+    s = _torch_sfx(x)
+    if out is None:
+        out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = getattr(lib(), f"dsp_pow_compress_dev_{s}")(C.c_void_p(out.data_ptr()), C.c_void_p(x.data_ptr()), x.numel(),
+                                                         float(p), float(preg), _stream_ptr(x))
+    _check(rc, f"dsp_pow_compress_dev_{s}")
     return out
 
 

@@ -143,7 +143,7 @@ int stft_desc(const char *fn, FrameDesc &d, size_t B, size_t N, size_t ldx, size
     d.rd_shift = 0; d.tbl = nullptr;
     d.L = (int)L; d.nfft = (int)nfft; d.W = (int)W;
     d.stp = (int)(stp > (size_t)INT_MAX ? (size_t)INT_MAX : stp);      // stp > INT_MAX implies W <= 1
-    d.edge = 0; d.mn0 = mn0 != 0; d.amp = amp != 0; d.lg = lg != 0; d.B = (int)B;
+    d.edge = 0; d.mn0 = mn0 != 0; d.epi = Epilogue{amp != 0, lg != 0, 0, 0.0, 0.0}; d.B = (int)B;
     return 0;
 }
 
@@ -178,7 +178,7 @@ int flt_desc(const char *fn, int dev, FrameDesc &d, size_t B, size_t N, size_t l
     d = FrameDesc{};
     d.N = (long long)N; d.ldx = (long long)ldx;
     d.L = (int)L; d.nfft = (int)nfft; d.W = (int)W; d.edge = 1;
-    d.mn0 = mn0 != 0; d.amp = amp != 0; d.lg = lg != 0; d.B = (int)B;
+    d.mn0 = mn0 != 0; d.epi = Epilogue{amp != 0, lg != 0, 0, 0.0, 0.0}; d.B = (int)B;
     d.tbl = nullptr; d.ss0 = 0; d.rd_shift = 0; d.stp = 1;
     if (W == 0) { return 0; }
 
@@ -333,6 +333,94 @@ int stft_flt_dev(const char *fn, T *Yd, const T *Xd, const T *wd, size_t B, size
     return run_fused<T>(fn, dev, Yd, Xd, wd, d, (hipStream_t)stream);
 }
 
+// power compression as an epilogue; checks and messages of reference c/pow_compress.c:25-26,30-46
+template <typename T>
+int pc_epilogue(const char *fn, T p, T preg, Epilogue &e)
+{
+    if (p < T(0) || p > T(1)) { fprintf(stderr, "error in %s: pow must be in [0.0 1.0]\n", fn); return 1; }
+    if (preg < T(0)) { fprintf(stderr, "error in %s: preg must be nonnegative\n", fn); return 1; }
+    e.p = (double)p; e.preg = (double)preg;
+    if (p == T(1)) { e.pc = 1; }
+    else if (p == T(0)) { e.pc = 2; }
+    else if (p == T(0.5)) { e.pc = 3; }
+    else if (std::fabs(p - T(1) / T(3)) <= (T)FLT_EPSILON) { e.pc = 4; }
+    else { e.pc = 5; }
+    return 0;
+}
+
+template <typename T>
+int stft_pc_dev(const char *fn, T *Yd, const T *Xd, const T *wd, size_t B, size_t N, size_t ldx, size_t L, size_t nfft, size_t stp,
+                int snip_edges, int mn0, int amp, int lg, T p, T preg, void *stream)
+{
+    FrameDesc d; size_t W;
+    if (stft_desc(fn, d, B, N, ldx, L, nfft, stp, snip_edges, mn0, amp, lg, W)) { return 1; }
+    if (pc_epilogue<T>(fn, p, preg, d.epi)) { return 1; }
+    if (W == 0 || B == 0) { return 0; }
+    if (B > 1 && ldx < N) { fprintf(stderr, "error in %s: ldx must be >= N\n", fn); return 1; }
+    if (!Yd || !Xd || !wd) { fprintf(stderr, "error in %s: null device pointer\n", fn); return 1; }
+    int dev;
+    if (use_device(fn, dev)) { return 1; }
+    return run_fused<T>(fn, dev, Yd, Xd, wd, d, (hipStream_t)stream);
+}
+
+template <typename T>
+int stft_pc_host(const char *fn, T *Y, const T *X, const T *win, size_t B, size_t N, size_t ldx, size_t L, size_t nfft, size_t stp,
+                 int snip_edges, int mn0, int amp, int lg, T p, T preg)
+{
+    FrameDesc d; size_t W;
+    if (stft_desc(fn, d, B, N, ldx, L, nfft, stp, snip_edges, mn0, amp, lg, W)) { return 1; }
+    if (pc_epilogue<T>(fn, p, preg, d.epi)) { return 1; }
+    if (W == 0 || B == 0) { return 0; }
+    int dev;
+    if (use_device(fn, dev)) { return 1; }
+    return run_fused_host<T>(fn, dev, Y, X, win, d, (B - 1) * ldx + N);
+}
+
+template <typename T>
+int pow_compress_host(const char *fn, T *Y, const T *X, size_t N, T p, T preg)
+{
+    Epilogue e{0, 0, 0, 0.0, 0.0};
+    if (pc_epilogue<T>(fn, p, preg, e)) { return 1; }
+    if (N == 0) { return 0; }
+    int dev;
+    if (use_device(fn, dev)) { return 1; }
+    DevState &st = g_dev[dev];
+    std::lock_guard<std::mutex> lk(st.ws_mu);
+    void *dx;
+    if (ws_reserve(fn, st, 0, N * sizeof(T), dx)) { return 1; }
+    HIPCHK(fn, hipMemcpy(dx, X, N * sizeof(T), hipMemcpyHostToDevice));
+    HIPCHK(fn, launch_pow_compress<T>((T *)dx, (const T *)dx, N, e, nullptr));
+    HIPCHK(fn, hipMemcpy(Y, dx, N * sizeof(T), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+template <typename T>
+int pow_compress_dev(const char *fn, T *Yd, const T *Xd, size_t N, T p, T preg, void *stream)
+{
+    Epilogue e{0, 0, 0, 0.0, 0.0};
+    if (pc_epilogue<T>(fn, p, preg, e)) { return 1; }
+    if (N == 0) { return 0; }
+    if (!Yd || !Xd) { fprintf(stderr, "error in %s: null device pointer\n", fn); return 1; }
+    int dev;
+    if (use_device(fn, dev)) { return 1; }
+    HIPCHK(fn, launch_pow_compress<T>(Yd, Xd, N, e, (hipStream_t)stream));
+    return 0;
+}
+
+// frequency axis of the spectrogram, F values computed on the host (reference c/get_stft_freqs.c:21-33)
+template <typename T>
+int stft_freqs(const char *fn, T *Y, size_t nfft, size_t F, T fs)
+{
+    if (F > nfft) { fprintf(stderr, "error in %s: F must be <= nfft\n", fn); return 1; }
+    if (F == 0) { return 0; }
+    const size_t nyq = nfft / 2u + 1u;
+    const T finc = fs / (T)nfft;
+    Y[0] = T(0);
+    for (size_t f = 1; f < F && f < nyq; ++f) { Y[f] = (T)f * finc; }
+    for (size_t f = nyq > 1 ? nyq : 1; f < F; ++f) { Y[f] = -finc * (T)(nfft - f); }
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // unfused entry points
 // ------------------------------------------------------------------------------------------------
@@ -476,6 +564,25 @@ int stft_flt_s(float *Y, const float *X1, const float *X2, const size_t N, const
 { return stft_flt_host<float>("stft_flt_s", Y, X1, X2, N, L, W, nfft, c0, stp, mn0, amp, lg); }
 int stft_flt_d(double *Y, const double *X1, const double *X2, const size_t N, const size_t L, const size_t W, const size_t nfft, const double c0, const double stp, const int mn0, const int amp, const int lg)
 { return stft_flt_host<double>("stft_flt_d", Y, X1, X2, N, L, W, nfft, c0, stp, mn0, amp, lg); }
+
+int pow_compress_s(float *Y, const float *X, const size_t N, const float p, const float preg) { return pow_compress_host<float>("pow_compress_s", Y, X, N, p, preg); }
+int pow_compress_d(double *Y, const double *X, const size_t N, const double p, const double preg) { return pow_compress_host<double>("pow_compress_d", Y, X, N, p, preg); }
+int pow_compress_inplace_s(float *X, const size_t N, const float p, const float preg) { return pow_compress_host<float>("pow_compress_inplace_s", X, X, N, p, preg); }
+int pow_compress_inplace_d(double *X, const size_t N, const double p, const double preg) { return pow_compress_host<double>("pow_compress_inplace_d", X, X, N, p, preg); }
+int get_stft_freqs_s(float *Y, const size_t nfft, const size_t F, const float fs) { return stft_freqs<float>("get_stft_freqs_s", Y, nfft, F, fs); }
+int get_stft_freqs_d(double *Y, const size_t nfft, const size_t F, const double fs) { return stft_freqs<double>("get_stft_freqs_d", Y, nfft, F, fs); }
+int dsp_pow_compress_dev_s(float *Y_dev, const float *X_dev, const size_t N, const float p, const float preg, void *stream)
+{ return pow_compress_dev<float>("dsp_pow_compress_dev_s", Y_dev, X_dev, N, p, preg, stream); }
+int dsp_pow_compress_dev_d(double *Y_dev, const double *X_dev, const size_t N, const double p, const double preg, void *stream)
+{ return pow_compress_dev<double>("dsp_pow_compress_dev_d", Y_dev, X_dev, N, p, preg, stream); }
+int dsp_stft_pc_batch_dev_s(float *Y_dev, const float *X_dev, const float *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, const float p, const float preg, void *stream)
+{ return stft_pc_dev<float>("dsp_stft_pc_batch_dev_s", Y_dev, X_dev, win_dev, B, N, ldx, L, nfft, stp, snip_edges, mn0, amp, lg, p, preg, stream); }
+int dsp_stft_pc_batch_dev_d(double *Y_dev, const double *X_dev, const double *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, const double p, const double preg, void *stream)
+{ return stft_pc_dev<double>("dsp_stft_pc_batch_dev_d", Y_dev, X_dev, win_dev, B, N, ldx, L, nfft, stp, snip_edges, mn0, amp, lg, p, preg, stream); }
+int dsp_stft_pc_batch_s(float *Y, const float *X, const float *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, const float p, const float preg)
+{ return stft_pc_host<float>("dsp_stft_pc_batch_s", Y, X, win, B, N, ldx, L, nfft, stp, snip_edges, mn0, amp, lg, p, preg); }
+int dsp_stft_pc_batch_d(double *Y, const double *X, const double *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, const double p, const double preg)
+{ return stft_pc_host<double>("dsp_stft_pc_batch_d", Y, X, win, B, N, ldx, L, nfft, stp, snip_edges, mn0, amp, lg, p, preg); }
 
 int fft_power_c(float *Y, const float *X, const size_t N) { return fft_power_host<float>("fft_power_c", Y, X, N); }
 int fft_power_z(double *Y, const double *X, const size_t N) { return fft_power_host<double>("fft_power_z", Y, X, N); }

@@ -85,8 +85,8 @@ __global__ __launch_bounds__(256) void stft_pow2_kernel(T *__restrict__ Y, const
             const T ar = zr + mr, ai = zi - mi, br = zr - mr, bi = zi + mi;
             const T tr = br * wi + bi * wr, ti = bi * wi - br * wr;
             const T pr = ar + tr, pi = ai + ti, qr = ar - tr, qi = ai - ti;
-            y[k] = power_epilogue(T(0.25) * (pr * pr + pi * pi), d.amp, d.lg);
-            y[M - k] = power_epilogue(T(0.25) * (qr * qr + qi * qi), d.amp, d.lg);
+            y[k] = power_epilogue(T(0.25) * (pr * pr + pi * pi), d.epi);
+            y[M - k] = power_epilogue(T(0.25) * (qr * qr + qi * qi), d.epi);
         }
         __syncthreads();
     }
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void stft_direct_kernel(T *__restrict__ Y, con
             const T r = (T)re, i = (T)im;
             T p = r * r;
             if (f >= 1 && f + 2 <= F) { p += i * i; }
-            y[f] = power_epilogue(p, d.amp, d.lg);
+            y[f] = power_epilogue(p, d.epi);
         }
         __syncthreads();
     }
@@ -217,6 +217,23 @@ hipError_t launch_fft_power(T *Y, const T *X, size_t N, hipStream_t s)
     size_t grid = (N + 255) / 256;
     if (grid > 256 * 32) { grid = 256 * 32; }
     hipLaunchKernelGGL(fft_power_kernel<T>, dim3((unsigned)grid), dim3(256), 0, s, Y, X, N);
+    return hipGetLastError();
+}
+
+// reference c/pow_compress.c:23-50 -- Y[n] = f(X[n] + preg), f by the exponent; 2 elements of traffic per value
+template <typename T>
+__global__ __launch_bounds__(256) void pow_compress_kernel(T *__restrict__ Y, const T *__restrict__ X, const size_t N, const Epilogue e)
+{
+    for (size_t n = (size_t)blockIdx.x * 256 + threadIdx.x; n < N; n += (size_t)gridDim.x * 256) { Y[n] = power_epilogue(X[n], e); }
+}
+
+template <typename T>
+hipError_t launch_pow_compress(T *Y, const T *X, size_t N, const Epilogue &e, hipStream_t s)
+{
+    if (N == 0) { return hipSuccess; }
+    size_t grid = (N + 255) / 256;
+    if (grid > 256 * 32) { grid = 256 * 32; }
+    hipLaunchKernelGGL(pow_compress_kernel<T>, dim3((unsigned)grid), dim3(256), 0, s, Y, X, N, e);
     return hipGetLastError();
 }
 
@@ -376,6 +393,8 @@ hipError_t launch_r2hc(T *Y, const T *X, const T *tw, size_t V, size_t K, size_t
     return hipGetLastError();
 }
 
+template hipError_t launch_pow_compress<float>(float *, const float *, size_t, const Epilogue &, hipStream_t);
+template hipError_t launch_pow_compress<double>(double *, const double *, size_t, const Epilogue &, hipStream_t);
 template hipError_t launch_fft_power<float>(float *, const float *, size_t, hipStream_t);
 template hipError_t launch_fft_power<double>(double *, const double *, size_t, hipStream_t);
 template hipError_t launch_frames<float>(float *, const float *, const FrameDesc &, int, hipStream_t);

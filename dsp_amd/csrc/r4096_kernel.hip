@@ -32,7 +32,7 @@ struct R4096Args {
     long long rd_shift;
     const int *tbl;
     int L, W, stp, edge;
-    int amp, lg;
+    Epilogue epi;
     int frames;           // B * W
 };
 
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
                 if (m > 0) { B = cx_mul<float>(B, W64C[8 * m], W64C[8 * m + 1]); }
                 const C2 Tw = cx_mul<float>(B, owm[c]);
                 p[c] = cx_norm<float>(A + Tw); q[c] = cx_norm<float>(A - Tw);
-                if (EPI) { p[c] = power_epilogue(p[c], a.amp, a.lg); q[c] = power_epilogue(q[c], a.amp, a.lg); }
+                if (EPI) { p[c] = power_epilogue(p[c], a.epi); q[c] = power_epilogue(q[c], a.epi); }
             }
             const int k0 = 4 * lane + 256 * m;
 #if R4096_ABLATE & 1
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         }
         if (lane == 0) {
             float p = 4.0f * cx_norm<float>(ex[1024]);     // bin 1024 pairs with itself (Z holds half values)
-            if (EPI) { p = power_epilogue(p, a.amp, a.lg); }
+            if (EPI) { p = power_epilogue(p, a.epi); }
             y[1024] = p;
         }
         R4096_STAMP(5);
@@ -388,9 +388,9 @@ hipError_t launch_stft_r4096(float *Y, const float *X, const float *win, const f
 {
     R4096Args a{};
     a.ldx = d.ldx; a.N = d.N; a.ss0 = d.ss0; a.rd_shift = d.rd_shift; a.tbl = d.tbl;
-    a.L = d.L; a.W = d.W; a.stp = d.stp; a.edge = d.edge; a.amp = d.amp; a.lg = d.lg;
+    a.L = d.L; a.W = d.W; a.stp = d.stp; a.edge = d.edge; a.epi = d.epi;
     a.frames = d.B * d.W;
-    const bool full = d.L == 4096, epi = d.amp || d.lg;
+    const bool full = d.L == 4096, epi = d.epi.any();
 #define DSP_R4096(F_, M_, E_) launch_r4096_inst<F_, M_, E_>(Y, X, win, tw, a, s)
     if (full) {
         if (d.mn0) { return epi ? DSP_R4096(true, true, true) : DSP_R4096(true, true, false); }

@@ -24,7 +24,7 @@ struct R512FastArgs {
     int ss0;              // start of frame 0
     int rd_shift;         // edge == 1: samples are read at n - rd_shift
     int edge;             // 0 reflect, 1 zero
-    int amp, lg;
+    Epilogue epi;
     int sps;              // steps (groups of 4 consecutive frames) per signal
     int steps;            // B * sps
 };
@@ -337,8 +337,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
         }
         if (EPI) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { pw[i] = power_epilogue(pw[i], a.amp, a.lg); }
-            p128 = power_epilogue(p128, a.amp, a.lg);
+            for (int i = 0; i < 16; ++i) { pw[i] = power_epilogue(pw[i], a.epi); }
+            p128 = power_epilogue(p128, a.epi);
         }
         wave_sync();                                       // every lane has read its tile row: reuse the region
         {
@@ -460,10 +460,10 @@ hipError_t launch_stft_r512_fast(T *Y, const T *X, const T *win, const T *tw, co
 {
     R512FastArgs a{};
     a.ldx = d.ldx; a.N = (int)d.N; a.L = d.L; a.W = d.W; a.stp = d.stp; a.ss0 = (int)d.ss0;
-    a.rd_shift = (int)d.rd_shift; a.edge = d.edge; a.amp = d.amp; a.lg = d.lg;
+    a.rd_shift = (int)d.rd_shift; a.edge = d.edge; a.epi = d.epi;
     a.sps = (d.W + 3) / 4;
     a.steps = d.B * a.sps;
-    const bool epi = d.amp || d.lg;
+    const bool epi = d.epi.any();
     const bool nr13 = d.L > 384 && d.L <= 416;
 #define DSP_R512F(NR_, MN0_, EPI_) launch_fast_inst<T, NR_, MN0_, EPI_>(Y, X, win, tw, a, s)
     if (nr13) {

@@ -171,12 +171,12 @@ __global__ __launch_bounds__(256) void stft_r512_kernel(T *__restrict__ Y, const
                     const T ar = z.x + zm.x, ai = z.y - zm.y, br = z.x - zm.x, bi = z.y + zm.y;
                     const T tr = br * wi + bi * wr, ti = bi * wi - br * wr;
                     const T pr = ar + tr, pi = ai + ti, qr = ar - tr, qi = ai - ti;
-                    y[k] = power_epilogue(pr * pr + pi * pi, d.amp, d.lg);
-                    y[M - k] = power_epilogue(qr * qr + qi * qi, d.amp, d.lg);
+                    y[k] = power_epilogue(pr * pr + pi * pi, d.epi);
+                    y[M - k] = power_epilogue(qr * qr + qi * qi, d.epi);
                 }
                 if (lane == 0) {
                     const T2 z = zf[128];       // bin 128 pairs with itself: X = conj(Z) (Z holds half values)
-                    y[128] = power_epilogue(T(4) * (z.x * z.x + z.y * z.y), d.amp, d.lg);
+                    y[128] = power_epilogue(T(4) * (z.x * z.x + z.y * z.y), d.epi);
                 }
             }
             wave_sync();

@@ -11,6 +11,15 @@ namespace dsp {
 //   table mode  (tbl != nullptr):  ss_w = tbl[2w], read start rd_w = tbl[2w+1]
 // edge == 0: sample index n = ss_w + l is reflected into [0,N) (reference c/stft.c:113)
 // edge == 1: value is 0 unless 0 <= n < N, else X[n - (ss_w - rd_w)]  (reference c/stft_flt.c:66-88)
+// What happens to a power value before it is stored: [sqrt] -> [log] -> [power compression].
+// pc selects the compression of reference c/pow_compress.c:23-50 applied to v + preg:
+// 0 none, 1 identity (v + preg), 2 log, 3 sqrt, 4 cbrt, 5 pow(., p).
+struct Epilogue {
+    int amp, lg, pc;
+    double p, preg;
+    bool any() const { return amp || lg || pc; }
+};
+
 struct FrameDesc {
     long long N;         // samples per signal
     long long ldx;       // elements between the starts of consecutive signals
@@ -22,7 +31,8 @@ struct FrameDesc {
     int W;               // frames per signal
     int stp;             // uniform mode: hop in samples
     int edge;
-    int mn0, amp, lg;
+    int mn0;
+    Epilogue epi;
     int B;               // signals
 };
 
@@ -43,13 +53,20 @@ __device__ __forceinline__ void frame_origin(const FrameDesc &d, int w, long lon
     else { ss = d.ss0 + (long long)w * d.stp; rdoff = d.rd_shift; }
 }
 
-// sqrt / log epilogue of the power value (reference c/stft.c:86-95)
+// epilogue of the power value (reference c/stft.c:86-95, then c/pow_compress.c:28-47)
 template <typename T>
-__device__ __forceinline__ T power_epilogue(T p, int amp, int lg)
+__device__ __forceinline__ T power_epilogue(T v, const Epilogue &e)
 {
-    if (amp) { p = sqrt(p); }
-    if (lg) { p = log(p); }
-    return p;
+    if (e.amp) { v = sqrt(v); }
+    if (e.lg) { v = log(v); }
+    if (e.pc) {
+        v += (T)e.preg;
+        if (e.pc == 2) { v = log(v); }
+        else if (e.pc == 3) { v = sqrt(v); }
+        else if (e.pc == 4) { v = cbrt(v); }
+        else if (e.pc == 5) { v = pow(v, (T)e.p); }
+    }
+    return v;
 }
 
 template <typename T> struct vec2;
@@ -77,6 +94,7 @@ template <typename T> hipError_t launch_stft_r512_fast(T *Y, const T *X, const T
 
 // ---- unfused kernels (unfused_kernels.hip) ----------------------------------------------------
 template <typename T> hipError_t launch_fft_power(T *Y, const T *X, size_t N, hipStream_t s);
+template <typename T> hipError_t launch_pow_compress(T *Y, const T *X, size_t N, const Epilogue &e, hipStream_t s);
 template <typename T> hipError_t launch_frames(T *Y, const T *X, const FrameDesc &d, int E, hipStream_t s);
 template <typename T> hipError_t launch_apply_win(T *Y, const T *X1, const T *X2, size_t N, size_t stride_dim, size_t len_dim, int cplx, hipStream_t s);
 template <typename T> hipError_t launch_r2hc(T *Y, const T *X, const T *tw, size_t V, size_t K, size_t Lx, size_t nfft, int pow2, T scale, hipStream_t s);

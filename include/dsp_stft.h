@@ -74,6 +74,20 @@ int apply_win_inplace_z (double *X1, const double *X2, const size_t R, const siz
 int fft_fftw_r2hc_s (float *Y, const float *X, const size_t R, const size_t C, const size_t S, const size_t H, const int iscolmajor, const size_t dim, const size_t nfft, const int sc);
 int fft_fftw_r2hc_d (double *Y, const double *X, const size_t R, const size_t C, const size_t S, const size_t H, const int iscolmajor, const size_t dim, const size_t nfft, const int sc);
 
+/* reference c/pow_compress.c:17-20.  Y[n] = f(X[n] + preg) over N values: p == 1 identity, p == 0
+ * natural log, p == 0.5 sqrt, |p - 1/3| <= FLT_EPSILON cbrt, otherwise pow(., p); p in [0,1],
+ * preg >= 0.  The step after stft in the reference's pipeline (the fused form is in part 2). */
+int pow_compress_s (float *Y, const float *X, const size_t N, const float p, const float preg);
+int pow_compress_d (double *Y, const double *X, const size_t N, const double p, const double preg);
+int pow_compress_inplace_s (float *X, const size_t N, const float p, const float preg);
+int pow_compress_inplace_d (double *X, const size_t N, const double p, const double preg);
+
+/* reference c/get_stft_freqs.c:13-14.  The first F bin frequencies of an nfft-point STFT at sample
+ * rate fs: f*fs/nfft up to Nyquist, negative frequencies after it.  F <= nfft values, computed on
+ * the host (metadata, not part of the transform). */
+int get_stft_freqs_s (float *Y, const size_t nfft, const size_t F, const float fs);
+int get_stft_freqs_d (double *Y, const size_t nfft, const size_t F, const double fs);
+
 
 /* ===================== Part 2: additions (no counterpart in the reference) ===================== */
 
@@ -102,6 +116,18 @@ int dsp_stft_flt_batch_dev_d (double *Y_dev, const double *X_dev, const double *
 /* Batched host-pointer forms: X[b*ldx + n], Y[b][W][F]; copies in, computes, copies out. */
 int dsp_stft_batch_s (float *Y, const float *X, const float *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg);
 int dsp_stft_batch_d (double *Y, const double *X, const double *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg);
+
+/* STFT with the power compression of pow_compress_s/_d fused into the store of every value
+ * (power -> [sqrt] -> [log] -> compress): the spectrogram is written once instead of written,
+ * re-read and re-written.  Device-pointer and host-pointer batched forms. */
+int dsp_stft_pc_batch_dev_s (float *Y_dev, const float *X_dev, const float *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, const float p, const float preg, void *stream);
+int dsp_stft_pc_batch_dev_d (double *Y_dev, const double *X_dev, const double *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, const double p, const double preg, void *stream);
+int dsp_stft_pc_batch_s (float *Y, const float *X, const float *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, const float p, const float preg);
+int dsp_stft_pc_batch_d (double *Y, const double *X, const double *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, const double p, const double preg);
+
+/* Device-resident pow_compress over N values (Y_dev may equal X_dev), enqueued on `stream`. */
+int dsp_pow_compress_dev_s (float *Y_dev, const float *X_dev, const size_t N, const float p, const float preg, void *stream);
+int dsp_pow_compress_dev_d (double *Y_dev, const double *X_dev, const size_t N, const double p, const double preg, void *stream);
 
 /* Device-resident fft_power over N interleaved complex values, enqueued on `stream`. */
 int dsp_fft_power_dev_c (float *Y_dev, const float *X_dev, const size_t N, void *stream);

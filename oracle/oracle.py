@@ -266,6 +266,31 @@ def ref_window_univar_flt(x, win, W, c0, stp):
     return rc, Y
 
 
+def pow_compress(x, p, preg, use_ref=False):
+    """Oracle for pow_compress_s/_d (reference c/pow_compress.c); use_ref runs the reference's own code."""
+    x = np.ascontiguousarray(x)
+    s, _ = _sfx(x.dtype)
+    Y = np.zeros_like(x)
+    f = getattr(ref(), f"pow_compress_{s}") if use_ref else getattr(orc(), f"orc_pow_compress_{s}")
+    ft = C.c_float if s == "s" else C.c_double
+    f.restype = _int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, ft, ft]
+    rc = f(_ptr(Y), _ptr(x), x.size, float(p), float(preg))
+    return rc, Y
+
+
+def get_stft_freqs(nfft, F, fs, dtype, use_ref=False):
+    """Oracle for get_stft_freqs_s/_d (reference c/get_stft_freqs.c)."""
+    s, _ = _sfx(dtype)
+    Y = np.zeros(F, dtype=dtype)
+    f = getattr(ref(), f"get_stft_freqs_{s}") if use_ref else getattr(orc(), f"orc_get_stft_freqs_{s}")
+    ft = C.c_float if s == "s" else C.c_double
+    f.restype = _int
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, ft]
+    rc = f(_ptr(Y), nfft, F, float(fs))
+    return rc, Y
+
+
 def ref_window(name, L, dtype, norm=0):
     """reference window generators c/hann.c, c/hamming.c, c/povey.c, c/blackmanharris.c."""
     s, _ = _sfx(dtype)

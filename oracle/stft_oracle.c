@@ -29,6 +29,9 @@
 #define ROUND roundf
 #define SQRT sqrtf
 #define LOG logf
+#define FABS fabsf
+#define CBRT cbrtf
+#define POW powf
 #define EPS FLT_EPSILON
 #include "stft_oracle_impl.h"
 #undef T
@@ -37,6 +40,9 @@
 #undef ROUND
 #undef SQRT
 #undef LOG
+#undef FABS
+#undef CBRT
+#undef POW
 #undef EPS
 
 #define T double
@@ -45,6 +51,9 @@
 #define ROUND round
 #define SQRT sqrt
 #define LOG log
+#define FABS fabs
+#define CBRT cbrt
+#define POW pow
 #define EPS DBL_EPSILON
 #include "stft_oracle_impl.h"
 #undef T
@@ -53,6 +62,9 @@
 #undef ROUND
 #undef SQRT
 #undef LOG
+#undef FABS
+#undef CBRT
+#undef POW
 #undef EPS
 
 /* number of frames; reference c/stft.c:40 */

@@ -394,6 +394,36 @@ int FNC(fft_power)(T *Y, const T *X, const size_t N)
     return 0;
 }
 
+
+/* ---- pow_compress_s / _d : reference c/pow_compress.c:23-50, :53-80 ---- */
+int FN(pow_compress)(T *Y, const T *X, const size_t N, const T p, const T preg)
+{
+    if (p<(T)0 || p>(T)1) { fprintf(stderr,"error in %s: pow must be in [0.0 1.0]\n", STR(FN(pow_compress))); return 1; }
+    if (preg<(T)0) { fprintf(stderr,"error in %s: preg must be nonnegative\n", STR(FN(pow_compress))); return 1; }
+    for (size_t n=0u; n<N; ++n)
+    {
+        const T v = X[n] + preg;
+        if (p==(T)1) { Y[n] = v; }
+        else if (p==(T)0) { Y[n] = LOG(v); }
+        else if (p==(T)0.5) { Y[n] = SQRT(v); }
+        else if (FABS(p-(T)1/(T)3)<=(T)FLT_EPSILON) { Y[n] = CBRT(v); }
+        else { Y[n] = POW(v,p); }
+    }
+    return 0;
+}
+
+/* ---- get_stft_freqs_s / _d : reference c/get_stft_freqs.c:17-31, :34-48 ---- */
+int FN(get_stft_freqs)(T *Y, const size_t nfft, const size_t F, const T fs)
+{
+    if (F>nfft) { fprintf(stderr,"error in %s: F must be <= nfft\n", STR(FN(get_stft_freqs))); return 1; }
+    const size_t Nyq = nfft/2u + 1u;
+    const T finc = fs/(T)nfft;
+    if (F>0u) { Y[0] = (T)0; }
+    for (size_t f=1u; f<F && f<Nyq; ++f) { Y[f] = (T)f * finc; }
+    for (size_t f=(Nyq>1u)?Nyq:1u; f<F; ++f) { Y[f] = -finc * (T)(nfft-f); }
+    return 0;
+}
+
 #undef CAT_
 #undef CAT
 #undef FN

@@ -442,3 +442,72 @@ def test_full_size_long_window_4096(O, D):
     Y2 = D.stft_dev(x * 2, win, 1024)
     torch.cuda.synchronize()
     assert torch.equal(Y2, Y * 4)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_pow_compress_and_freqs(O, D, dt):
+    """pow_compress_* is a pure element-wise map: element-wise relative bound (a few ulp of the
+    library functions: 4e-6 float32, 2e-14 float64; exact for the identity branch)."""
+    x = np.abs(signal(31, 20000, dt)) * dt(3)
+    x[:4] = 0
+    rtol = 4e-6 if dt == np.float32 else 2e-14
+    for p, preg in [(1.0, 0.25), (0.0, 1e-6), (0.5, 0.0), (1.0 / 3.0, 1e-3), (0.3, 1e-3), (0.85, 0.0)]:
+        rc, ref = O.pow_compress(x, p, preg)
+        y = D.pow_compress(x, p, preg)
+        if p == 1.0:
+            assert np.array_equal(y, ref)
+        else:
+            np.testing.assert_allclose(y, ref, rtol=rtol, atol=rtol)
+        z = x.copy()
+        assert D.pow_compress(z, p, preg, inplace=True) is z and np.array_equal(z, y)
+    for p, preg in [(-0.1, 0.0), (1.5, 0.0), (0.5, -1.0)]:
+        with pytest.raises(D.DspError):
+            D.pow_compress(x, p, preg)
+    for nfft, F, fs in [(512, 257, 16000.0), (512, 400, 44100.0), (4096, 2049, 48000.0)]:
+        assert np.array_equal(D.get_stft_freqs(nfft, F, fs, dt), O.get_stft_freqs(nfft, F, fs, dt)[1])
+    with pytest.raises(D.DspError):
+        D.get_stft_freqs(8, 9, 1.0, dt)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_fused_power_compression_matches_two_step_oracle(O, D, dt):
+    """dsp_stft_pc_batch_*: STFT with the compression fused into the store == oracle stft followed by oracle
+    pow_compress, in every kernel family (512 fast and generic, 4096, a direct-DFT size, a generic power of two)."""
+    import torch
+
+    def undo(y, p, preg):
+        y = y.astype(np.float64)
+        with np.errstate(over="ignore"):
+            v = np.exp(y) if p == 0.0 else y if p == 1.0 else np.power(y, 1.0 / p)
+        return (v - preg).astype(dt)
+
+    for (N, L, stp, nfft) in [(16000, 400, 160, 512), (7013, 512, 33, 512), (30000, 4096, 1024, 4096), (3000, 300, 160, 300), (5000, 400, 160, 1024)]:
+        x = np.stack([signal(N + b, N, dt) for b in range(3)])
+        win = D.povey(L, dt) if L != 4096 else D.blackmanharris(L, dt)
+        for p, preg, flags in [(0.0, 1e-6, (0, 0, 0)), (0.5, 0.0, (1, 0, 0)), (1.0 / 3.0, 1e-3, (0, 0, 0)), (0.3, 1e-2, (0, 1, 0)), (1.0, 0.5, (0, 0, 0))]:
+            ref = []
+            for b in range(3):
+                rc, P = O.stft(x[b], win, stp, nfft, 0, *flags, exact=(nfft <= 1024))
+                rc2, Pc = O.pow_compress(P, p, preg)
+                assert rc == 0 and rc2 == 0
+                ref.append(Pc)
+            ref = np.stack(ref)
+            for generic in (False, True):
+                D.force_generic(generic)
+                try:
+                    Y = D.stft_pc_batch(x, win, p, preg, stp, False, *[bool(f) for f in flags], nfft=nfft)
+                    Yd = D.stft_pc_dev(torch.from_numpy(x).cuda(), torch.from_numpy(win).cuda(), p, preg, stp, False,
+                                       *[bool(f) for f in flags], nfft=nfft).cpu().numpy()
+                finally:
+                    D.force_generic(False)
+                assert np.array_equal(Y, Yd)
+                # compared in the domain the bound is stated for: the compression is undone in float64
+                # first (a cube root turns a 1e-7-of-the-maximum rounding residue into 5e-3 of it)
+                check_spec(O, undo(Y, p, preg), undo(ref, p, preg))
+    with pytest.raises(D.DspError):
+        D.stft_pc_batch(np.zeros((1, 2000), dt), np.ones(400, dt), 1.5)
+    # device-resident pow_compress, in place
+    t = torch.rand(100000, dtype=torch.float32 if dt == np.float32 else torch.float64, device="cuda")
+    ref = O.pow_compress(t.cpu().numpy(), 0.3, 1e-3)[1]
+    out = D.pow_compress_dev(t, 0.3, 1e-3, out=t)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=4e-6 if dt == np.float32 else 2e-14)

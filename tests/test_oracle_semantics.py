@@ -131,3 +131,21 @@ def test_fast_mode_close_to_exact(O):
         rc, Ye = O.stft(x, win, 160, 512, exact=True)
         rc, Yf = O.stft(x, win, 160, 512, exact=False)
         assert O.normalised_err(Yf, Ye) <= tol
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_pow_compress_and_freqs_oracle_equals_reference(O, dt):
+    """The restatements of c/pow_compress.c and c/get_stft_freqs.c return the reference's own bits."""
+    x = np.abs(np.random.default_rng(3).standard_normal(5000)).astype(dt)
+    x[:3] = 0
+    for p, preg in [(1.0, 0.0), (1.0, 0.5), (0.0, 1e-6), (0.5, 0.0), (1.0 / 3.0, 1e-3), (0.3, 1e-3), (0.9, 0.0)]:
+        rc, a = O.pow_compress(x, p, preg)
+        rc2, b = O.pow_compress(x, p, preg, use_ref=True)
+        assert rc == 0 and rc2 == 0 and np.array_equal(a, b, equal_nan=True)
+    for p, preg in [(-0.1, 0.0), (1.1, 0.0), (0.5, -1.0)]:
+        assert O.pow_compress(x, p, preg)[0] == 1 and O.pow_compress(x, p, preg, use_ref=True)[0] == 1
+    for nfft, F, fs in [(512, 257, 16000.0), (512, 512, 16000.0), (512, 300, 44100.0), (4096, 2049, 48000.0), (2, 2, 1.0), (8, 1, 8.0)]:
+        rc, a = O.get_stft_freqs(nfft, F, fs, dt)
+        rc2, b = O.get_stft_freqs(nfft, F, fs, dt, use_ref=True)
+        assert rc == 0 and rc2 == 0 and np.array_equal(a, b)
+    assert O.get_stft_freqs(8, 9, 1.0, dt)[0] == 1 and O.get_stft_freqs(8, 9, 1.0, dt, use_ref=True)[0] == 1

@@ -41,6 +41,11 @@ SIGNATURES = {
     "dsp_stft_flt_batch_dev_d": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _d, _d, _int, _int, _int, _vp]),
     "dsp_stft_batch_s": (_int, _BHOST), "dsp_stft_batch_d": (_int, _BHOST),
     "dsp_fft_power_dev_c": (_int, [_vp, _vp, _sz, _vp]), "dsp_fft_power_dev_z": (_int, [_vp, _vp, _sz, _vp]),
+    "hann_s": (_int, [_vp, _sz, _sz]), "hann_d": (_int, [_vp, _sz, _sz]),
+    "hamming_s": (_int, [_vp, _sz, _sz]), "hamming_d": (_int, [_vp, _sz, _sz]),
+    "povey_s": (_int, [_vp, _sz, _sz]), "povey_d": (_int, [_vp, _sz, _sz]),
+    "blackmanharris_s": (_int, [_vp, _sz, _sz]), "blackmanharris_d": (_int, [_vp, _sz, _sz]),
+    "dsp_window_dev_s": (_int, [_vp, _int, _sz, _sz, _vp]), "dsp_window_dev_d": (_int, [_vp, _int, _sz, _sz, _vp]),
     "pow_compress_s": (_int, [_vp, _vp, _sz, _f, _f]), "pow_compress_d": (_int, [_vp, _vp, _sz, _d, _d]),
     "pow_compress_inplace_s": (_int, [_vp, _sz, _f, _f]), "pow_compress_inplace_d": (_int, [_vp, _sz, _d, _d]),
     "get_stft_freqs_s": (_int, [_vp, _sz, _sz, _f]), "get_stft_freqs_d": (_int, [_vp, _sz, _sz, _d]),

@@ -189,6 +189,32 @@ def fft_power(xc):
     return Y
 
 
+WINDOW_IDS = {"hann": 0, "hamming": 1, "povey": 2, "blackmanharris": 3}
+
+
+def window(name, L, norm=0, dtype=np.float32):
+    """hann_s/_d, hamming_s/_d, povey_s/_d, blackmanharris_s/_d: the window computed by the library."""
+    if name not in WINDOW_IDS:
+        raise ValueError(f"unknown window {name}")
+    s = _real_sfx(np.dtype(dtype))
+    Y = np.empty(L, dtype=dtype)
+    rc = getattr(lib(), f"{name}_{s}")(_p(Y), L, norm)
+    _check(rc, f"{name}_{s}")
+    return Y
+
+
+def window_dev(name, L, norm=0, dtype=None, device="cuda"):
+    """dsp_window_dev_s/_d: the window as a device tensor, enqueued on torch's current stream."""
+    import torch
+    dtype = torch.float32 if dtype is None else dtype
+    out = torch.empty(L, dtype=dtype, device=device)
+    s = _torch_sfx(out)
+    with torch.cuda.device(out.device):
+        rc = getattr(lib(), f"dsp_window_dev_{s}")(C.c_void_p(out.data_ptr()), WINDOW_IDS[name], L, norm, _stream_ptr(out))
+    _check(rc, f"dsp_window_dev_{s}")
+    return out
+
+
 def pow_compress(x, p, preg=0.0, inplace=False):
     """pow_compress_s / _d (and _inplace_): f(x + preg) element-wise, f chosen by the exponent p in [0, 1]."""
     x = np.ascontiguousarray(x)

@@ -407,6 +407,40 @@ int pow_compress_dev(const char *fn, T *Yd, const T *Xd, size_t N, T p, T preg, 
     return 0;
 }
 
+// window generators: checks and message of reference c/hann.c:23
+const char *const WINDOW_NAMES[4] = {"hann", "hamming", "povey", "blackmanharris"};
+
+template <typename T>
+int window_host(const char *fn, T *Y, size_t L, size_t norm, int kind)
+{
+    if (norm > 3u) { fprintf(stderr, "error in %s: norm must be in {0,1,2,3}\n", fn); return 1; }
+    if (L > (size_t)INT_MAX / 4) { fprintf(stderr, "error in %s: problem size exceeds the supported index range\n", fn); return 1; }
+    if (L == 0) { return 0; }
+    int dev;
+    if (use_device(fn, dev)) { return 1; }
+    DevState &st = g_dev[dev];
+    std::lock_guard<std::mutex> lk(st.ws_mu);
+    void *dy;
+    if (ws_reserve(fn, st, 1, L * sizeof(T), dy)) { return 1; }
+    HIPCHK(fn, launch_window<T>((T *)dy, L, kind, (int)norm, nullptr));
+    HIPCHK(fn, hipMemcpy(Y, dy, L * sizeof(T), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+template <typename T>
+int window_dev(const char *fn, T *Yd, int kind, size_t L, size_t norm, void *stream)
+{
+    if (kind < 0 || kind > 3) { fprintf(stderr, "error in %s: window must be 0 (hann), 1 (hamming), 2 (povey) or 3 (blackmanharris)\n", fn); return 1; }
+    if (norm > 3u) { fprintf(stderr, "error in %s: norm must be in {0,1,2,3}\n", fn); return 1; }
+    if (L > (size_t)INT_MAX / 4) { fprintf(stderr, "error in %s: problem size exceeds the supported index range\n", fn); return 1; }
+    if (L == 0) { return 0; }
+    if (!Yd) { fprintf(stderr, "error in %s: null device pointer\n", fn); return 1; }
+    int dev;
+    if (use_device(fn, dev)) { return 1; }
+    HIPCHK(fn, launch_window<T>(Yd, L, kind, (int)norm, (hipStream_t)stream));
+    return 0;
+}
+
 // frequency axis of the spectrogram, F values computed on the host (reference c/get_stft_freqs.c:21-33)
 template <typename T>
 int stft_freqs(const char *fn, T *Y, size_t nfft, size_t F, T fs)
@@ -565,6 +599,16 @@ int stft_flt_s(float *Y, const float *X1, const float *X2, const size_t N, const
 int stft_flt_d(double *Y, const double *X1, const double *X2, const size_t N, const size_t L, const size_t W, const size_t nfft, const double c0, const double stp, const int mn0, const int amp, const int lg)
 { return stft_flt_host<double>("stft_flt_d", Y, X1, X2, N, L, W, nfft, c0, stp, mn0, amp, lg); }
 
+int hann_s(float *Y, const size_t L, const size_t norm) { return window_host<float>("hann_s", Y, L, norm, 0); }
+int hann_d(double *Y, const size_t L, const size_t norm) { return window_host<double>("hann_d", Y, L, norm, 0); }
+int hamming_s(float *Y, const size_t L, const size_t norm) { return window_host<float>("hamming_s", Y, L, norm, 1); }
+int hamming_d(double *Y, const size_t L, const size_t norm) { return window_host<double>("hamming_d", Y, L, norm, 1); }
+int povey_s(float *Y, const size_t L, const size_t norm) { return window_host<float>("povey_s", Y, L, norm, 2); }
+int povey_d(double *Y, const size_t L, const size_t norm) { return window_host<double>("povey_d", Y, L, norm, 2); }
+int blackmanharris_s(float *Y, const size_t L, const size_t norm) { return window_host<float>("blackmanharris_s", Y, L, norm, 3); }
+int blackmanharris_d(double *Y, const size_t L, const size_t norm) { return window_host<double>("blackmanharris_d", Y, L, norm, 3); }
+int dsp_window_dev_s(float *Y_dev, const int window, const size_t L, const size_t norm, void *stream) { return window_dev<float>("dsp_window_dev_s", Y_dev, window, L, norm, stream); }
+int dsp_window_dev_d(double *Y_dev, const int window, const size_t L, const size_t norm, void *stream) { return window_dev<double>("dsp_window_dev_d", Y_dev, window, L, norm, stream); }
 int pow_compress_s(float *Y, const float *X, const size_t N, const float p, const float preg) { return pow_compress_host<float>("pow_compress_s", Y, X, N, p, preg); }
 int pow_compress_d(double *Y, const double *X, const size_t N, const double p, const double preg) { return pow_compress_host<double>("pow_compress_d", Y, X, N, p, preg); }
 int pow_compress_inplace_s(float *X, const size_t N, const float p, const float preg) { return pow_compress_host<float>("pow_compress_inplace_s", X, X, N, p, preg); }

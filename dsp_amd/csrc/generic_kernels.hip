@@ -237,6 +237,57 @@ hipError_t launch_pow_compress(T *Y, const T *X, size_t N, const Epilogue &e, hi
     return hipGetLastError();
 }
 
+// Window generators (reference c/hann.c:21-41, c/hamming.c:20-40, c/povey.c:21-41,
+// c/blackmanharris.c:22-42): symmetric windows of period L-1, first half from the formula in T
+// arithmetic, centre of an odd length forced to 1, second half mirrored; norm 1 divides by the sum,
+// 2 by the root of the sum of squares, 3 by the element L/2.  One workgroup; sums in double.
+template <typename T>
+__global__ __launch_bounds__(256) void window_kernel(T *__restrict__ Y, const int L, const int kind, const int norm)
+{
+    __shared__ double red[256];
+    const int tid = threadIdx.x, h = L / 2;
+    const T p = (T)(6.283185307179586476925286766559 / (double)(L - 1));
+    for (int l = tid; l < h; l += 256) {
+        T v;
+        if (kind == 0) { v = T(0.5) - T(0.5) * cos((T)l * p); }
+        else if (kind == 1) { v = T(0.54) - T(0.46) * cos((T)l * p); }
+        else if (kind == 2) { v = pow(T(0.5) - T(0.5) * cos((T)l * p), T(0.85)); }
+        else { v = T(0.35875) - T(0.48829) * cos((T)l * p) + T(0.14128) * cos((T)(2 * l) * p) - T(0.01168) * cos((T)(3 * l) * p); }
+        Y[l] = v;
+        Y[L - 1 - l] = v;
+    }
+    if ((L & 1) && tid == 0) { Y[h] = T(1); }
+    if (norm == 0) { return; }
+    __syncthreads();
+    double nrm;
+    if (norm == 3) {
+        nrm = (double)Y[h];
+    } else {
+        double acc = 0.0;
+        for (int l = tid; l < L; l += 256) { const double v = (double)Y[l]; acc += (norm == 1) ? v : v * v; }
+        red[tid] = acc;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) { red[tid] += red[tid + o]; }
+            __syncthreads();
+        }
+        nrm = (norm == 1) ? red[0] : sqrt(red[0]);
+    }
+    __syncthreads();
+    const T d = (T)nrm;
+    for (int l = tid; l < L; l += 256) { Y[l] = Y[l] / d; }
+}
+
+template <typename T>
+hipError_t launch_window(T *Y, size_t L, int kind, int norm, hipStream_t s)
+{
+    if (L == 0) { return hipSuccess; }
+    hipLaunchKernelGGL(window_kernel<T>, dim3(1), dim3(256), 0, s, Y, (int)L, kind, norm);
+    return hipGetLastError();
+}
+template hipError_t launch_window<float>(float *, size_t, int, int, hipStream_t);
+template hipError_t launch_window<double>(double *, size_t, int, int, hipStream_t);
+
 // reference c/frame_univar.c:41-95, c/frame_univar_flt.c:29-91 -- Y[w][l] = X[index(w,l)], E values
 // of T per sample (1 real, 2 complex)
 template <typename T>

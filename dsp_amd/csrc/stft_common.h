@@ -93,6 +93,7 @@ hipError_t launch_stft_r4096(float *Y, const float *X, const float *win, const f
 template <typename T> hipError_t launch_stft_r512_fast(T *Y, const T *X, const T *win, const T *tw, const FrameDesc &d, hipStream_t s);
 
 // ---- unfused kernels (unfused_kernels.hip) ----------------------------------------------------
+template <typename T> hipError_t launch_window(T *Y, size_t L, int kind, int norm, hipStream_t s);
 template <typename T> hipError_t launch_fft_power(T *Y, const T *X, size_t N, hipStream_t s);
 template <typename T> hipError_t launch_pow_compress(T *Y, const T *X, size_t N, const Epilogue &e, hipStream_t s);
 template <typename T> hipError_t launch_frames(T *Y, const T *X, const FrameDesc &d, int E, hipStream_t s);

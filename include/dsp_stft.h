@@ -74,6 +74,19 @@ int apply_win_inplace_z (double *X1, const double *X2, const size_t R, const siz
 int fft_fftw_r2hc_s (float *Y, const float *X, const size_t R, const size_t C, const size_t S, const size_t H, const int iscolmajor, const size_t dim, const size_t nfft, const int sc);
 int fft_fftw_r2hc_d (double *Y, const double *X, const size_t R, const size_t C, const size_t S, const size_t H, const int iscolmajor, const size_t dim, const size_t nfft, const int sc);
 
+/* reference c/hann.c:15-16, c/hamming.c:15-16, c/povey.c:15-16, c/blackmanharris.c:16-17.  The
+ * window X2 of stft: symmetric, period L-1, L values; norm 0 none, 1 unit sum, 2 unit energy,
+ * 3 divided by element L/2.  (The reference's _c/_z forms, which interleave a zero imaginary
+ * part, are not provided: stft takes real windows only.) */
+int hann_s (float *Y, const size_t L, const size_t norm);
+int hann_d (double *Y, const size_t L, const size_t norm);
+int hamming_s (float *Y, const size_t L, const size_t norm);
+int hamming_d (double *Y, const size_t L, const size_t norm);
+int povey_s (float *Y, const size_t L, const size_t norm);
+int povey_d (double *Y, const size_t L, const size_t norm);
+int blackmanharris_s (float *Y, const size_t L, const size_t norm);
+int blackmanharris_d (double *Y, const size_t L, const size_t norm);
+
 /* reference c/pow_compress.c:17-20.  Y[n] = f(X[n] + preg) over N values: p == 1 identity, p == 0
  * natural log, p == 0.5 sqrt, |p - 1/3| <= FLT_EPSILON cbrt, otherwise pow(., p); p in [0,1],
  * preg >= 0.  The step after stft in the reference's pipeline (the fused form is in part 2). */
@@ -128,6 +141,11 @@ int dsp_stft_pc_batch_d (double *Y, const double *X, const double *win, const si
 /* Device-resident pow_compress over N values (Y_dev may equal X_dev), enqueued on `stream`. */
 int dsp_pow_compress_dev_s (float *Y_dev, const float *X_dev, const size_t N, const float p, const float preg, void *stream);
 int dsp_pow_compress_dev_d (double *Y_dev, const double *X_dev, const size_t N, const double p, const double preg, void *stream);
+
+/* Window generated straight into device memory (window: 0 hann, 1 hamming, 2 povey,
+ * 3 blackmanharris), enqueued on `stream`: the X2 of the *_dev entry points without a host array. */
+int dsp_window_dev_s (float *Y_dev, const int window, const size_t L, const size_t norm, void *stream);
+int dsp_window_dev_d (double *Y_dev, const int window, const size_t L, const size_t norm, void *stream);
 
 /* Device-resident fft_power over N interleaved complex values, enqueued on `stream`. */
 int dsp_fft_power_dev_c (float *Y_dev, const float *X_dev, const size_t N, void *stream);

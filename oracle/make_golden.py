@@ -101,6 +101,10 @@ def main():
         for wname in ("hann", "hamming", "povey", "blackmanharris"):
             for L in (1, 2, 7, 400, 401):
                 d[f"{wname}.{L}"] = O.ref_window(wname, L, dt)
+            for L in (7, 400, 401):
+                for norm in (1, 2, 3):
+                    d[f"{wname}.{L}.n{norm}"] = O.ref_window(wname, L, dt, norm)
+        d["blackmanharris.4096"] = O.ref_window("blackmanharris", 4096, dt)
         np.savez_compressed(os.path.join(OUT, f"ref_windows_{tag}.npz"), **d)
 
         # complex framing / windowing (frame_univar_c/z, frame_univar_flt_c/z, apply_win_c/z in place form)

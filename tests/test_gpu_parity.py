@@ -511,3 +511,38 @@ def test_fused_power_compression_matches_two_step_oracle(O, D, dt):
     ref = O.pow_compress(t.cpu().numpy(), 0.3, 1e-3)[1]
     out = D.pow_compress_dev(t, 0.3, 1e-3, out=t)
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=4e-6 if dt == np.float32 else 2e-14)
+
+
+@pytest.mark.parametrize("tag", ["s", "d"])
+def test_window_generators_against_reference_fixtures(D, tag):
+    """hann/hamming/povey/blackmanharris computed on the device vs what the reference's own generators
+    returned (fixtures), all four norms.  Bound: absolute, relative to the window's largest element:
+    3e-7 float32 (the reference evaluates cosf/powf in float, a few ulp from the device's), 1e-14 float64;
+    for norms 1 and 2, whose divisor the reference accumulates serially in T over L terms, 3e-6 and 1e-13."""
+    import torch
+    g = load_golden(f"ref_windows_{tag}.npz")
+    dt = np.float32 if tag == "s" else np.float64
+    tol = 3e-7 if tag == "s" else 1e-14
+    seen = 0
+    for key in g.files:
+        parts = key.split(".")
+        name, L = parts[0], int(parts[1])
+        norm = int(parts[2][1:]) if len(parts) > 2 else 0
+        ref = g[key]
+        y = D.window(name, L, norm, dt)
+        assert y.dtype == ref.dtype and y.shape == ref.shape
+        scale = np.max(np.abs(ref)) if L else 1.0
+        bound = tol * (10 if norm in (1, 2) else 1)
+        assert np.max(np.abs(y.astype(np.float64) - ref)) <= bound * scale, (key, np.max(np.abs(y - ref)) / scale)
+        yd = D.window_dev(name, L, norm, torch.float32 if tag == "s" else torch.float64).cpu().numpy()
+        assert np.array_equal(y, yd)
+        seen += 1
+    assert seen >= 57
+    with pytest.raises(D.DspError):
+        D.window("hann", 16, 4, dt)
+    assert D.window("hann", 0, 0, dt).size == 0
+    # a generated window drives the transform like a host-made one
+    x = signal(3, 8000, dt)
+    win = D.window_dev("povey", 400, 0, torch.float32 if tag == "s" else torch.float64)
+    Y = D.stft_dev(torch.from_numpy(x).cuda(), win, 160).cpu().numpy()[0]
+    assert np.array_equal(Y, D.stft(x, win.cpu().numpy(), 160))

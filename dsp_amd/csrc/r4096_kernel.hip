@@ -46,6 +46,15 @@ typedef float4 __attribute__((aligned(4))) float4_u;
 #ifndef R4096_ABLATE
 #define R4096_ABLATE 0          // diagnostic builds: bit 0 = no row stores, bit 1 = no sample loads
 #endif
+#ifndef R4096_EARLY
+#define R4096_EARLY 8           // loads (of 16 per frame) issued before pass 2 instead of after it
+#endif
+#ifndef R4096_LOCKSTEP
+#define R4096_LOCKSTEP 1        // 1: the waves of a workgroup meet at a barrier every R4096_LOCK_EVERY frames
+#endif
+#ifndef R4096_LOCK_EVERY
+#define R4096_LOCK_EVERY 2      // power of two
+#endif
 #ifndef R4096_STAMPS
 #define R4096_STAMPS 0          // diagnostic builds: 1 = per-phase s_memtime sums into g_r4096_stamps
 #endif
@@ -134,7 +143,12 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
     const int xcd = blockIdx.x & 7, nwg_x = gridDim.x >> 3;
     const int f_lo = (int)((long long)a.frames * xcd / 8), f_hi = (int)((long long)a.frames * (xcd + 1) / 8);
     const int fstride = nwg_x * R4096_WAVES;
+    // Static round-robin inside the range.  The 8 waves of a workgroup take 8 neighbouring frames per
+    // round and meet at a barrier every other round (below): without it they drift apart by more
+    // rounds than the L2 holds, the 3/4 of its samples that a frame shares with its neighbours miss,
+    // and 2.6x the samples come from HBM (measured with FETCH_SIZE).
     int fid = f_lo + (blockIdx.x >> 3) * R4096_WAVES + wv;
+    int nfid = fid + fstride;
     if (fid >= f_hi) { return; }
 
     // where frame f lies: output row, first sample, and whether all 4096 samples can be read in place
@@ -152,18 +166,26 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         return q;
     };
     C2 ze[16], zo[16];      // loads: columns 2 l4 (ze) and 2 l4 + 1 (zo), rows 2 i + up; later: the two halves of a 32-point transform
+    // The first NE of a frame's 16 loads are issued a whole pass earlier than the rest, into registers of
+    // their own (the transform registers are still busy then); the window step reads them from there.
+    constexpr int NE = R4096_EARLY;
+    float4 pre[NE > 0 ? NE : 1];
     const int loff = 128 * up + 4 * l4;                     // first sample of the lane inside a frame; row i adds 256
     // raw samples of a frame that lies inside its signal: 16 coalesced 1-KiB wave loads
-    auto load_inside = [&](const Where &q) {
+    auto put = [&](int i, const float4 v) {
+        if (i < NE) { pre[i] = v; } else { ze[i] = C2{v.x, v.y}; zo[i] = C2{v.z, v.w}; }
+    };
+    auto load_inside = [&](const Where &q, const int i0, const int i1) {
         const float *src = q.xb + (q.ss - q.rdoff) + loff;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
+            if (i < i0 || i >= i1) { continue; }
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
 #if R4096_ABLATE & 2
             if (a.N == -12345)
 #endif
             if (FULL || 256 * i < L) { v = *reinterpret_cast<const float4_u *>(src + 256 * i); }
-            ze[i] = C2{v.x, v.y}; zo[i] = C2{v.z, v.w};
+            put(i, v);
         }
     };
     // a frame that crosses an edge of its signal: gather sample by sample into the (idle) tile first
@@ -176,14 +198,13 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         wave_sync();
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const float4 v = *reinterpret_cast<const float4 *>(stage + loff + 256 * i);
-            ze[i] = C2{v.x, v.y}; zo[i] = C2{v.z, v.w};
+            put(i, *reinterpret_cast<const float4 *>(stage + loff + 256 * i));
         }
         asm volatile("" ::: "memory");                 // keeps these LDS reads from being merged with load_inside's into flat loads
     };
 
     Where cur = locate(fid);
-    if (cur.inside) { load_inside(cur); } else { load_edge(cur); }
+    if (cur.inside) { load_inside(cur, 0, 16); } else { load_edge(cur); }
 #if R4096_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory");
@@ -193,6 +214,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
     // Returns false after the last frame.  The first frame runs in a copy of its own, so that inside
     // the loop every wait on the prefetched samples sees the same sequence of loads followed by this
     // frame's stores and lets the stores drain in the background.
+    int iter = 0;
     auto frame = [&]() __attribute__((always_inline)) -> bool {
         // ---------------- pass 1: window, 32-point FFT over n1 ----------------
         {
@@ -202,6 +224,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const float4 hh = *reinterpret_cast<const float4 *>(wtab + loff + 256 * i);
+                if (i < NE) { ze[i] = C2{pre[i].x, pre[i].y}; zo[i] = C2{pre[i].z, pre[i].w}; }
                 if (!FULL) {                                 // keep data past the window out (0 * NaN)
                     ze[i].x = (256 * i < lim) ? ze[i].x : 0.f;
                     ze[i].y = (256 * i + 1 < lim) ? ze[i].y : 0.f;
@@ -270,6 +293,14 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
             }
         }
         wave_sync();
+        // where the next frame lies; its first loads go out now, under pass 2
+        const bool more = nfid < f_hi;
+        const Where nxt = locate(more ? nfid : fid);
+
+#if R4096_LOCKSTEP
+        if ((iter++ & (R4096_LOCK_EVERY - 1)) == 0) { __builtin_amdgcn_s_barrier(); }   // the workgroup's 8 waves request neighbouring frames together
+#endif
+        if (NE > 0 && nxt.inside) { load_inside(nxt, 0, NE); }
         R4096_STAMP(1);
 
         // ---------------- pass 2: lane = row (k1, parity): 32-point FFT ----------------
@@ -292,10 +323,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         R4096_STAMP(3);
 
         // the registers are free from here on: start the next frame's loads under the split
-        const int nfid = fid + fstride;
-        const bool more = nfid < f_hi;
-        const Where nxt = locate(more ? nfid : fid);
-        if (nxt.inside) { load_inside(nxt); }
+        if (nxt.inside) { load_inside(nxt, NE, 16); }
         R4096_STAMP(4);
 
         // ---------------- split + power + store: lane handles bins k = 4 lane + c + 256 m and 2048 - k ----------------
@@ -339,6 +367,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         if (!nxt.inside) { load_edge(nxt); }
         cur = nxt;
         fid = nfid;
+        nfid += fstride;
         return true;
     };
 #if R4096_STAMPS

@@ -93,6 +93,9 @@ __device__ unsigned long long g_r512f_stamps[8192 * 8];
 #ifndef R512F_NOSTORE
 #define R512F_NOSTORE 0         // diagnostic builds: 1 = the row stores are compiled out
 #endif
+#ifndef R512F_LOCK_EVERY
+#define R512F_LOCK_EVERY 4      // n > 0 (power of two): the waves of a workgroup meet at a barrier every n steps
+#endif
 #ifndef R512F_ST4
 #define R512F_ST4 1             // 1: rows leave as 16-byte vector stores when the step's block is 16-byte aligned
 #endif
@@ -239,7 +242,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
     // flight; then commit that span to LDS and issue the fetch of the one after.  The stores of a
     // step are unconditional and fixed in number, so the wait for the in-flight span leaves them
     // outstanding instead of draining the store queue.
+#if R512F_LOCK_EVERY
+    int it = 0;
+#endif
     while (true) {
+#if R512F_LOCK_EVERY
+        if ((it++ & (R512F_LOCK_EVERY - 1)) == 0) { __builtin_amdgcn_s_barrier(); }
+#endif
         // ---- pass 1: lane (frame f, column n2 = j): 16-point FFT over the rows n1 ----
         C zz[16];
 #if R512F_ABLATE != 1

@@ -408,8 +408,6 @@ int pow_compress_dev(const char *fn, T *Yd, const T *Xd, size_t N, T p, T preg, 
 }
 
 // window generators: checks and message of reference c/hann.c:23
-const char *const WINDOW_NAMES[4] = {"hann", "hamming", "povey", "blackmanharris"};
-
 template <typename T>
 int window_host(const char *fn, T *Y, size_t L, size_t norm, int kind)
 {

@@ -91,6 +91,10 @@ template <typename T> __device__ __forceinline__ cx<T> cx_mul(const cx<T> a, con
     return cx_fma(cx_swap(a), cx<T>{-s, s}, t);
 }
 template <typename T> __device__ __forceinline__ cx<T> cx_mul(const cx<T> a, const cx<T> w) { return cx_mul<T>(a, w.x, w.y); }
+// the two halves of cx_mul, for callers that interleave several independent products: on gfx950 a packed
+// fma that consumes the packed product issued just before it costs an extra s_nop
+template <typename T> __device__ __forceinline__ cx<T> cx_mul_first(const cx<T> a, const cx<T> w) { return a * cx<T>{w.x, w.x}; }
+template <typename T> __device__ __forceinline__ cx<T> cx_mul_second(const cx<T> a, const cx<T> w, const cx<T> t) { return cx_fma(cx_swap(a), cx<T>{-w.y, w.y}, t); }
 // |a|^2
 template <typename T> __device__ __forceinline__ T cx_norm(const cx<T> a) { const cx<T> q = a * a; return q.x + q.y; }
 

@@ -96,14 +96,8 @@ template <typename T>
 hipError_t launch_stft_pow2(T *Y, const T *X, const T *win, const T *tw, const FrameDesc &d, hipStream_t s)
 {
     const size_t lds = (size_t)d.nfft * sizeof(T) + 64;
-    static size_t granted = 0;
-    (void)hipGetLastError();
-    if (lds > 48 * 1024 && lds > granted) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&stft_pow2_kernel<T>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { return e; }
-        granted = lds;
-    }
+    static LdsGrant grant;
+    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_pow2_kernel<T>), lds, grant); e != hipSuccess) { return e; }
     const long long total = (long long)d.B * d.W;
     const int grid = (int)(total < 8192 ? total : 8192);
     hipLaunchKernelGGL(stft_pow2_kernel<T>, dim3(grid), dim3(256), lds, s, Y, X, win, tw, d);
@@ -172,14 +166,8 @@ template <typename T>
 hipError_t launch_stft_direct(T *Y, const T *X, const T *win, const T *tw, const FrameDesc &d, hipStream_t s)
 {
     const size_t lds = (size_t)d.L * sizeof(T) + 64;
-    static size_t granted = 0;
-    (void)hipGetLastError();
-    if (lds > 48 * 1024 && lds > granted) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&stft_direct_kernel<T>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { return e; }
-        granted = lds;
-    }
+    static LdsGrant grant;
+    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_direct_kernel<T>), lds, grant); e != hipSuccess) { return e; }
     const long long total = (long long)d.B * d.W;
     const int grid = (int)(total < 8192 ? total : 8192);
     hipLaunchKernelGGL(stft_direct_kernel<T>, dim3(grid), dim3(256), lds, s, Y, X, win, tw, d);
@@ -431,14 +419,8 @@ hipError_t launch_r2hc(T *Y, const T *X, const T *tw, size_t V, size_t K, size_t
 {
     if (V == 0) { return hipSuccess; }
     const size_t lds = (pow2 ? nfft : Lx) * sizeof(T) + 64;
-    static size_t granted = 0;
-    (void)hipGetLastError();
-    if (lds > 48 * 1024 && lds > granted) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&r2hc_kernel<T>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { return e; }
-        granted = lds;
-    }
+    static LdsGrant grant;
+    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&r2hc_kernel<T>), lds, grant); e != hipSuccess) { return e; }
     const size_t grid = V < 8192 ? V : 8192;
     hipLaunchKernelGGL(r2hc_kernel<T>, dim3((unsigned)grid), dim3(256), lds, s, Y, X, tw, V, K, Lx, (int)nfft, pow2, scale);
     return hipGetLastError();

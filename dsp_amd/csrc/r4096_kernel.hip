@@ -41,7 +41,7 @@ constexpr int R4096_WAVE_C = 64 * R4096_PITCH;          // complex slots per wav
 constexpr int R4096_WAVES = 8;                          // waves per workgroup (share the window table)
 typedef float2 __attribute__((aligned(4))) float2_u;    // frame starts are only 4-byte aligned
 typedef unsigned u2v __attribute__((ext_vector_type(2)));
-typedef float4 __attribute__((aligned(4))) float4_u;
+typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access at 4-byte alignment
 
 #ifndef R4096_ABLATE
 #define R4096_ABLATE 0          // diagnostic builds: bit 0 = no row stores, bit 1 = no sample loads
@@ -54,6 +54,9 @@ typedef float4 __attribute__((aligned(4))) float4_u;
 #endif
 #ifndef R4096_LOCK_EVERY
 #define R4096_LOCK_EVERY 2      // power of two
+#endif
+#ifndef R4096_INTERLEAVE
+#define R4096_INTERLEAVE 1         // 1: twiddle products of four rows are issued before the fmas that consume them
 #endif
 #ifndef R4096_STAMPS
 #define R4096_STAMPS 0          // diagnostic builds: 1 = per-phase s_memtime sums into g_r4096_stamps
@@ -180,12 +183,12 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             if (i < i0 || i >= i1) { continue; }
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4_u v = {0.f, 0.f, 0.f, 0.f};
 #if R4096_ABLATE & 2
             if (a.N == -12345)
 #endif
             if (FULL || 256 * i < L) { v = *reinterpret_cast<const float4_u *>(src + 256 * i); }
-            put(i, v);
+            put(i, make_float4(v.x, v.y, v.z, v.w));
         }
     };
     // a frame that crosses an edge of its signal: gather sample by sample into the (idle) tile first
@@ -267,6 +270,30 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         R4096_STAMP(0);
 
         // twiddle W2048^(n2 k1), k1 = 4 q + b
+#if R4096_INTERLEAVE
+        // four rows at a time, the products of a group before the fmas that consume them
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            C2 *zp[4];
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) { const int k1 = 4 * q + bb; zp[bb] = (k1 < 16) ? &ze[slot16(k1)] : &zo[slot16(k1 - 16)]; }
+            C2 t[4];
+#pragma unroll
+            for (int bb = 1; bb < 4; ++bb) { t[bb] = cx_mul_first<float>(*zp[bb], tb[bb]); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int bb = 1; bb < 4; ++bb) { *zp[bb] = cx_mul_second<float>(*zp[bb], tb[bb], t[bb]); }
+            if (q) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) { t[bb] = cx_mul_first<float>(*zp[bb], ta[q]); }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) { *zp[bb] = cx_mul_second<float>(*zp[bb], ta[q], t[bb]); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#else
 #pragma unroll
         for (int k1 = 1; k1 < 32; ++k1) {
             C2 &z = (k1 < 16) ? ze[slot16(k1)] : zo[slot16(k1 - 16)];
@@ -274,6 +301,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
             if (bb) { z = cx_mul<float>(z, tb[bb]); }
             if (q) { z = cx_mul<float>(z, ta[q]); }
         }
+#endif
         // first radix-2 stage of the 64-point transforms over n2: columns n2 and n2 + 32 sit 16 lanes
         // apart; one swap of rows k1 and k1 + 16 leaves the even 16-lane groups with row k1
         // (x = column n2, y = column n2 + 32) and the odd groups with row k1 + 16
@@ -353,8 +381,8 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
             if (a.N == -12345)
 #endif
             {
-                *reinterpret_cast<float4_u *>(y + k0) = make_float4(p[0], p[1], p[2], p[3]);
-                *reinterpret_cast<float4_u *>(y + M - 3 - k0) = make_float4(q[3], q[2], q[1], q[0]);
+                *reinterpret_cast<float4_u *>(y + k0) = float4_u{p[0], p[1], p[2], p[3]};
+                *reinterpret_cast<float4_u *>(y + M - 3 - k0) = float4_u{q[3], q[2], q[1], q[0]};
             }
         }
         if (lane == 0) {
@@ -398,14 +426,8 @@ template <bool FULL, bool MN0, bool EPI>
 static hipError_t launch_r4096_inst(float *Y, const float *X, const float *win, const float *tw, const R4096Args &a, hipStream_t s)
 {
     const size_t lds = 4096 * sizeof(float) + (size_t)R4096_WAVES * R4096_WAVE_C * sizeof(float2);
-    static bool granted = false;
-    (void)hipGetLastError();
-    if (!granted) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&stft_r4096_kernel<FULL, MN0, EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { return e; }
-        granted = true;
-    }
+    static LdsGrant grant;
+    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r4096_kernel<FULL, MN0, EPI>), lds, grant); e != hipSuccess) { return e; }
     long long grid = ((long long)a.frames + R4096_WAVES - 1) / R4096_WAVES;
     if (grid > 256) { grid = 256; }                      // one 8-wave workgroup per CU (151 KB of LDS each)
     grid = (grid + 7) & ~7ll;

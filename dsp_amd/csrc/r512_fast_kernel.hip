@@ -448,14 +448,8 @@ template <typename T, int NR, bool MN0, bool EPI>
 static hipError_t launch_fast_inst(T *Y, const T *X, const T *win, const T *tw, const R512FastArgs &a, hipStream_t s)
 {
     const size_t lds = (4 * (size_t)R512F_WAVE_ELEMS + 512 + 512) * sizeof(T);
-    static size_t granted = 0;
-    (void)hipGetLastError();
-    if (lds > 48 * 1024 && lds > granted) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&stft_r512_fast_kernel<T, NR, MN0, EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { return e; }
-        granted = lds;
-    }
+    static LdsGrant grant;
+    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r512_fast_kernel<T, NR, MN0, EPI>), lds, grant); e != hipSuccess) { return e; }
     static const int wgs_per_cu = [] { const char *e = getenv("DSP_R512F_WGS_PER_CU"); return e ? atoi(e) : 2; }();
     long long grid = ((long long)a.steps + 3) / 4;
     if (grid > 256ll * wgs_per_cu) { grid = 256ll * wgs_per_cu; }

@@ -201,14 +201,8 @@ hipError_t launch_stft_r512(T *Y, const T *X, const T *win, const T *tw, const F
     int xs_len = span ? 3 * d.stp + 512 : 2048;
     xs_len = (xs_len + 3) & ~3;                       // keeps the exchange region 16-byte aligned
     const size_t lds = ((WINREG ? 0 : 512) + 4 * ((size_t)xs_len + 4 * R512_EXF * 2)) * sizeof(T);
-    static size_t granted = 0;
-    (void)hipGetLastError();
-    if (lds > 48 * 1024 && lds > granted) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&stft_r512_kernel<T, WINREG>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { return e; }
-        granted = lds;
-    }
+    static LdsGrant grant;
+    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r512_kernel<T, WINREG>), lds, grant); e != hipSuccess) { return e; }
     // runs of `chunk` consecutive frames per wave: long enough to amortise the per-wave constants,
     // short enough that every CU gets several waves' worth of runs
     const long long frames = (long long)d.B * d.W;

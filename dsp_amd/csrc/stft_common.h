@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstddef>
+#include <atomic>
 #include <cstdint>
 
 namespace dsp {
@@ -78,6 +79,24 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// A kernel that needs more than 48 KB of dynamic LDS must be granted the size once per device (the
+// attribute belongs to the device's copy of the kernel).  One LdsGrant per kernel instantiation.
+struct LdsGrant { std::atomic<size_t> bytes[64]; };
+inline hipError_t ensure_lds(const void *kernel, size_t lds, LdsGrant &g)
+{
+    (void)hipGetLastError();                      // a stale error must not be taken for this launch's
+    if (lds <= 48 * 1024) { return hipSuccess; }
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) { return e; }
+    if (dev < 0 || dev >= 64) { return hipErrorInvalidDevice; }
+    if (lds <= g.bytes[dev].load()) { return hipSuccess; }
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { return e; }
+    g.bytes[dev].store(lds);
+    return hipSuccess;
 }
 
 // ---- launchers (stft_kernels.hip) -------------------------------------------------------------

@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default=DEFAULT, choices=sorted(WORKLOADS))
+    ap.add_argument("--ramp-ms", type=float, default=300.0, help="untimed device work before the warmup steps (clock ramp); 0 disables")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather", action="store_true", help="also time one RCCL all-gather of the output shards")
     ap.add_argument("--generic", action="store_true", help="force the generic kernel family (A/B)")
@@ -127,6 +128,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    # A GPU that has been idle takes some tens of milliseconds of work to reach its sustained clocks (the
+    # first ~50 launches of this workload run 8-10 % slower): bring it there before the W warmup steps, so
+    # that the K timed steps measure the steady state whatever K and W are.
+    if args.ramp_ms > 0:
+        t_r = time.perf_counter()
+        while (time.perf_counter() - t_r) * 1e3 < args.ramp_ms:
+            for _ in range(20):
+                run(y)
+            torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         run(y)
     sync_all()
@@ -172,7 +182,7 @@ def main():
         "config": {"workload": args.workload, "signals_per_gpu": B, "samples_per_signal": N, "window": wname, "L": L,
                    "hop": stp, "nfft": nfft, "frames_per_signal": W, "entry_point": "dsp_stft_flt_batch_dev" if kind == "flt" else "dsp_stft_batch_dev",
                    "kernel_family": "generic" if args.generic else {1: "direct", 2: "pow2", 3: "r512", 4: "r4096"}[dsp_amd.kernel_family(nfft, ndt)],
-                   "sharding": f"{world} ranks x {B} signals, no data-path collective"},
+                   "sharding": f"{world} ranks x {B} signals, no data-path collective", "device_ramp_ms": args.ramp_ms},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
                      "nominal_tflops_5NlogN": 5 * nfft * np.log2(nfft) * B * W / (kern_ms * 1e-3) / 1e12},

@@ -189,6 +189,29 @@ def fft_power(xc):
     return Y
 
 
+def window_univar(x, win, stp, snip_edges=False):
+    """window_univar_s / _d: frames of x, each multiplied by win; returns Y[W, L]."""
+    x = np.ascontiguousarray(x)
+    s = _real_sfx(x.dtype)
+    win = np.ascontiguousarray(win, dtype=x.dtype)
+    W = num_frames(x.size, win.size, stp, snip_edges)
+    Y = np.empty((W, win.size), dtype=x.dtype)
+    rc = getattr(lib(), f"window_univar_{s}")(_p(Y), _p(x), _p(win), x.size, win.size, stp, int(bool(snip_edges)))
+    _check(rc, f"window_univar_{s}")
+    return Y
+
+
+def window_univar_flt(x, win, W, c0, stp):
+    """window_univar_flt_s / _d: W zero-edged frames centred at round(c0 + w*stp), each multiplied by win."""
+    x = np.ascontiguousarray(x)
+    s = _real_sfx(x.dtype)
+    win = np.ascontiguousarray(win, dtype=x.dtype)
+    Y = np.empty((W, win.size), dtype=x.dtype)
+    rc = getattr(lib(), f"window_univar_flt_{s}")(_p(Y), _p(x), _p(win), x.size, win.size, W, float(c0), float(stp))
+    _check(rc, f"window_univar_flt_{s}")
+    return Y
+
+
 WINDOW_IDS = {"hann": 0, "hamming": 1, "povey": 2, "blackmanharris": 3}
 
 

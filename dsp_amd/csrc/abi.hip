@@ -474,24 +474,28 @@ int fft_power_host(const char *fn, T *Y, const T *X, size_t N)
 }
 
 template <typename T>
-int frames_host(const char *fn, T *Y, const T *X, const FrameDesc &d, int E, int dev)
+int frames_host(const char *fn, T *Y, const T *X, const FrameDesc &d, int E, int dev, const T *win = nullptr)
 {
     if (d.W == 0) { return 0; }
     DevState &st = g_dev[dev];
     std::lock_guard<std::mutex> lk(st.ws_mu);
-    void *dx, *dy;
+    void *dx, *dy, *dw = nullptr;
     const size_t xb = (size_t)d.N * E * sizeof(T), yb = (size_t)d.W * d.L * E * sizeof(T);
     if (ws_reserve(fn, st, 0, xb, dx)) { return 1; }
     if (ws_reserve(fn, st, 1, yb, dy)) { return 1; }
     HIPCHK(fn, hipMemcpy(dx, X, xb, hipMemcpyHostToDevice));
-    HIPCHK(fn, launch_frames<T>((T *)dy, (const T *)dx, d, E, nullptr));
+    if (win) {
+        if (ws_reserve(fn, st, 2, (size_t)d.L * sizeof(T), dw)) { return 1; }
+        HIPCHK(fn, hipMemcpy(dw, win, (size_t)d.L * sizeof(T), hipMemcpyHostToDevice));
+    }
+    HIPCHK(fn, launch_frames<T>((T *)dy, (const T *)dx, (const T *)dw, d, E, nullptr));
     HIPCHK(fn, hipMemcpy(Y, dy, yb, hipMemcpyDeviceToHost));
     return 0;
 }
 
 // reference c/frame_univar.c:43-48
 template <typename T>
-int frame_univar_host(const char *fn, T *Y, const T *X, size_t N, size_t L, size_t stp, int snip_edges, int E)
+int frame_univar_host(const char *fn, T *Y, const T *X, size_t N, size_t L, size_t stp, int snip_edges, int E, const T *win = nullptr)
 {
     if (L < 1u) { fprintf(stderr, "error in %s: L must be positive\n", fn); return 1; }
     if (stp < 1u) { fprintf(stderr, "error in %s: stp must be positive\n", fn); return 1; }
@@ -502,11 +506,11 @@ int frame_univar_host(const char *fn, T *Y, const T *X, size_t N, size_t L, size
     if (W == 0) { return 0; }
     int dev;
     if (use_device(fn, dev)) { return 1; }
-    return frames_host<T>(fn, Y, X, d, E, dev);
+    return frames_host<T>(fn, Y, X, d, E, dev, win);
 }
 
 template <typename T>
-int frame_univar_flt_host(const char *fn, T *Y, const T *X, size_t N, size_t L, size_t W, T c0, T stp, int E)
+int frame_univar_flt_host(const char *fn, T *Y, const T *X, size_t N, size_t L, size_t W, T c0, T stp, int E, const T *win = nullptr)
 {
     FrameDesc d;
     int dev = 0;
@@ -515,7 +519,7 @@ int frame_univar_flt_host(const char *fn, T *Y, const T *X, size_t N, size_t L, 
     }
     if (use_device(fn, dev)) { return 1; }
     if (flt_desc<T>(fn, dev, d, 1, N, N, L, W, 2, c0, stp, 0, 0, 0, 0, false)) { return 1; }
-    return frames_host<T>(fn, Y, X, d, E, dev);
+    return frames_host<T>(fn, Y, X, d, E, dev, win);
 }
 
 // reference c/apply_win.c:28-34
@@ -597,6 +601,14 @@ int stft_flt_s(float *Y, const float *X1, const float *X2, const size_t N, const
 int stft_flt_d(double *Y, const double *X1, const double *X2, const size_t N, const size_t L, const size_t W, const size_t nfft, const double c0, const double stp, const int mn0, const int amp, const int lg)
 { return stft_flt_host<double>("stft_flt_d", Y, X1, X2, N, L, W, nfft, c0, stp, mn0, amp, lg); }
 
+int window_univar_s(float *Y, const float *X1, const float *X2, const size_t N, const size_t L, const size_t stp, const int snip_edges)
+{ return frame_univar_host<float>("window_univar_s", Y, X1, N, L, stp, snip_edges, 1, X2); }
+int window_univar_d(double *Y, const double *X1, const double *X2, const size_t N, const size_t L, const size_t stp, const int snip_edges)
+{ return frame_univar_host<double>("window_univar_d", Y, X1, N, L, stp, snip_edges, 1, X2); }
+int window_univar_flt_s(float *Y, const float *X1, const float *X2, const size_t N, const size_t L, const size_t W, const float c0, const float stp)
+{ return frame_univar_flt_host<float>("window_univar_flt_s", Y, X1, N, L, W, c0, stp, 1, X2); }
+int window_univar_flt_d(double *Y, const double *X1, const double *X2, const size_t N, const size_t L, const size_t W, const double c0, const double stp)
+{ return frame_univar_flt_host<double>("window_univar_flt_d", Y, X1, N, L, W, c0, stp, 1, X2); }
 int hann_s(float *Y, const size_t L, const size_t norm) { return window_host<float>("hann_s", Y, L, norm, 0); }
 int hann_d(double *Y, const size_t L, const size_t norm) { return window_host<double>("hann_d", Y, L, norm, 0); }
 int hamming_s(float *Y, const size_t L, const size_t norm) { return window_host<float>("hamming_s", Y, L, norm, 1); }

@@ -279,7 +279,7 @@ template hipError_t launch_window<double>(double *, size_t, int, int, hipStream_
 // reference c/frame_univar.c:41-95, c/frame_univar_flt.c:29-91 -- Y[w][l] = X[index(w,l)], E values
 // of T per sample (1 real, 2 complex)
 template <typename T>
-__global__ __launch_bounds__(256) void frames_kernel(T *__restrict__ Y, const T *__restrict__ X, const FrameDesc d, const int E)
+__global__ __launch_bounds__(256) void frames_kernel(T *__restrict__ Y, const T *__restrict__ X, const T *__restrict__ win, const FrameDesc d, const int E)
 {
     const long long per_frame = (long long)d.L * E;
     const long long total = (long long)d.W * per_frame;
@@ -297,18 +297,18 @@ __global__ __launch_bounds__(256) void frames_kernel(T *__restrict__ Y, const T 
         } else if (n >= 0 && n < d.N) {
             v = X[(n - rdoff) * E + e];
         }
-        Y[i] = v;
+        Y[i] = win ? v * win[l] : v;            // window_univar*: real frames times a real window
     }
 }
 
 template <typename T>
-hipError_t launch_frames(T *Y, const T *X, const FrameDesc &d, int E, hipStream_t s)
+hipError_t launch_frames(T *Y, const T *X, const T *win, const FrameDesc &d, int E, hipStream_t s)
 {
     const long long total = (long long)d.W * d.L * E;
     if (total == 0) { return hipSuccess; }
     long long grid = (total + 255) / 256;
     if (grid > 256 * 32) { grid = 256 * 32; }
-    hipLaunchKernelGGL(frames_kernel<T>, dim3((unsigned)grid), dim3(256), 0, s, Y, X, d, E);
+    hipLaunchKernelGGL(frames_kernel<T>, dim3((unsigned)grid), dim3(256), 0, s, Y, X, win, d, E);
     return hipGetLastError();
 }
 
@@ -430,8 +430,8 @@ template hipError_t launch_pow_compress<float>(float *, const float *, size_t, c
 template hipError_t launch_pow_compress<double>(double *, const double *, size_t, const Epilogue &, hipStream_t);
 template hipError_t launch_fft_power<float>(float *, const float *, size_t, hipStream_t);
 template hipError_t launch_fft_power<double>(double *, const double *, size_t, hipStream_t);
-template hipError_t launch_frames<float>(float *, const float *, const FrameDesc &, int, hipStream_t);
-template hipError_t launch_frames<double>(double *, const double *, const FrameDesc &, int, hipStream_t);
+template hipError_t launch_frames<float>(float *, const float *, const float *, const FrameDesc &, int, hipStream_t);
+template hipError_t launch_frames<double>(double *, const double *, const double *, const FrameDesc &, int, hipStream_t);
 template hipError_t launch_apply_win<float>(float *, const float *, const float *, size_t, size_t, size_t, int, hipStream_t);
 template hipError_t launch_apply_win<double>(double *, const double *, const double *, size_t, size_t, size_t, int, hipStream_t);
 template hipError_t launch_r2hc<float>(float *, const float *, const float *, size_t, size_t, size_t, size_t, int, float, hipStream_t);

@@ -115,7 +115,8 @@ template <typename T> hipError_t launch_stft_r512_fast(T *Y, const T *X, const T
 template <typename T> hipError_t launch_window(T *Y, size_t L, int kind, int norm, hipStream_t s);
 template <typename T> hipError_t launch_fft_power(T *Y, const T *X, size_t N, hipStream_t s);
 template <typename T> hipError_t launch_pow_compress(T *Y, const T *X, size_t N, const Epilogue &e, hipStream_t s);
-template <typename T> hipError_t launch_frames(T *Y, const T *X, const FrameDesc &d, int E, hipStream_t s);
+// win != nullptr (E == 1 only): every frame is multiplied by the L window values
+template <typename T> hipError_t launch_frames(T *Y, const T *X, const T *win, const FrameDesc &d, int E, hipStream_t s);
 template <typename T> hipError_t launch_apply_win(T *Y, const T *X1, const T *X2, size_t N, size_t stride_dim, size_t len_dim, int cplx, hipStream_t s);
 template <typename T> hipError_t launch_r2hc(T *Y, const T *X, const T *tw, size_t V, size_t K, size_t Lx, size_t nfft, int pow2, T scale, hipStream_t s);
 

@@ -54,6 +54,13 @@ int frame_univar_flt_d (double *Y, const double *X, const size_t N, const size_t
 int frame_univar_flt_c (float *Y, const float *X, const size_t N, const size_t L, const size_t W, const float c0, const float stp);
 int frame_univar_flt_z (double *Y, const double *X, const size_t N, const size_t L, const size_t W, const double c0, const double stp);
 
+/* reference c/window_univar.c:35-36, c/window_univar_flt.c:23-24.  Framing and windowing in one
+ * step: Y[W][L] = frame_univar*(X1) times X2 along each frame (the real forms; X2 has L values). */
+int window_univar_s (float *Y, const float *X1, const float *X2, const size_t N, const size_t L, const size_t stp, const int snip_edges);
+int window_univar_d (double *Y, const double *X1, const double *X2, const size_t N, const size_t L, const size_t stp, const int snip_edges);
+int window_univar_flt_s (float *Y, const float *X1, const float *X2, const size_t N, const size_t L, const size_t W, const float c0, const float stp);
+int window_univar_flt_d (double *Y, const double *X1, const double *X2, const size_t N, const size_t L, const size_t W, const double c0, const double stp);
+
 /* reference c/apply_win.c:15-23.  Y = X1 .* X2, X2 (length L) broadcast along dim of the
  * R x C x S x H tensor X1, row- or column-major; the _c/_z forms multiply complex by complex.
  * The map is index-exact (X2 indexed by the coordinate along dim); the reference's strided branch

@@ -546,3 +546,30 @@ def test_window_generators_against_reference_fixtures(D, tag):
     win = D.window_dev("povey", 400, 0, torch.float32 if tag == "s" else torch.float64)
     Y = D.stft_dev(torch.from_numpy(x).cuda(), win, 160).cpu().numpy()[0]
     assert np.array_equal(Y, D.stft(x, win.cpu().numpy(), 160))
+
+
+@pytest.mark.parametrize("tag", ["s", "d"])
+def test_window_univar_against_reference_fixtures(O, D, tag):
+    """window_univar_* / window_univar_flt_* (framing and windowing in one step) are a copy and one
+    multiplication: bit-exact against what the reference's own code returned."""
+    g = load_golden(f"ref_chain_{tag}.npz")
+    seen = 0
+    for name in ["base", "short_multifold", "tiny"]:
+        x, win = g[f"{name}.x"], g[f"{name}.win"]
+        N, L, stp, nfft = (int(v) for v in g[f"{name}.params"])
+        for snip in (0, 1):
+            key = f"{name}.snip{snip}.windowed"
+            if key not in g:
+                continue
+            assert np.array_equal(D.window_univar(x, win, stp, bool(snip)), g[key])
+            seen += 1
+    assert seen >= 4
+    g = load_golden(f"ref_flt_{tag}.npz")
+    x, win = g["x"], g["win"]
+    for i, (c0, stp, W) in enumerate(g["cases"]):
+        if f"case{i}.windowed" in g:
+            assert np.array_equal(D.window_univar_flt(x, win, int(W), c0, stp), g[f"case{i}.windowed"])
+    rc, fr = O.frame_univar(x, win.size, 77, 0)
+    assert np.array_equal(D.window_univar(x, win, 77), fr * win[None, :])
+    with pytest.raises(D.DspError):
+        D.window_univar(x[:100], win, 10, True)

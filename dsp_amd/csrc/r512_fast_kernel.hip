@@ -58,7 +58,7 @@ template <> struct vec16<double> { using type = double2; static constexpr int n 
 #define R512F_ABLATE 0          // diagnostic builds: 1 = memory traffic only, 2 = no scalar-path stores, 3 = no FFT arithmetic, 4 = no exchange through LDS
 #endif
 #ifndef R512F_NT_STORE
-#define R512F_NT_STORE 0        // 1: spectrogram rows are stored with the non-temporal hint
+#define R512F_NT_STORE 1        // 1: spectrogram rows are stored with the non-temporal hint
 #endif
 #ifndef R512F_NT_LOAD
 #define R512F_NT_LOAD 0         // 1: signal spans are loaded with the non-temporal hint
@@ -380,7 +380,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
                     asm volatile("" :: "v"(v4.x), "v"(v4.y));
                     if (a.N == -12345) { reinterpret_cast<TV *>(yblk)[idx] = v4; }
 #else
+#if R512F_NT_STORE
+                    {
+                        typedef T vecnt __attribute__((ext_vector_type(VEC)));
+                        __builtin_nontemporal_store(reinterpret_cast<const vecnt *>(xs)[idx], reinterpret_cast<vecnt *>(yblk) + idx);
+                    }
+#else
                     reinterpret_cast<TV *>(yblk)[idx] = reinterpret_cast<const TV *>(xs)[idx];
+#endif
 #endif
                 }
             } else

@@ -54,16 +54,30 @@ __device__ __forceinline__ void frame_origin(const FrameDesc &d, int w, long lon
     else { ss = d.ss0 + (long long)w * d.stp; rdoff = d.rd_shift; }
 }
 
+// sqrt and natural log of a power value.  float: the hardware's 1-ulp v_sqrt_f32 and v_log_f32 (log2)
+// with the change of base carried in two parts, 3 instructions instead of the library's ~12 each
+// (16 values per lane and step: the library forms double the kernel's instruction count); inputs
+// below 2^-126 count as zero.  double: the library functions.
+__device__ __forceinline__ float epi_sqrt(float v) { return __builtin_amdgcn_sqrtf(v); }
+__device__ __forceinline__ double epi_sqrt(double v) { return sqrt(v); }
+__device__ __forceinline__ float epi_log(float v)
+{
+    const float l2 = __builtin_amdgcn_logf(v);                       // log2(v)
+    const float r = fmaf(l2, 0.693147182464599609375f, l2 * -1.9046542121259336e-09f);   // ln 2 = hi + lo
+    return (fabsf(l2) == __builtin_inff()) ? l2 : r;                  // log(0) = -inf, log(inf) = inf (inf - inf above)
+}
+__device__ __forceinline__ double epi_log(double v) { return log(v); }
+
 // epilogue of the power value (reference c/stft.c:86-95, then c/pow_compress.c:28-47)
 template <typename T>
 __device__ __forceinline__ T power_epilogue(T v, const Epilogue &e)
 {
-    if (e.amp) { v = sqrt(v); }
-    if (e.lg) { v = log(v); }
+    if (e.amp) { v = epi_sqrt(v); }
+    if (e.lg) { v = epi_log(v); }
     if (e.pc) {
         v += (T)e.preg;
-        if (e.pc == 2) { v = log(v); }
-        else if (e.pc == 3) { v = sqrt(v); }
+        if (e.pc == 2) { v = epi_log(v); }
+        else if (e.pc == 3) { v = epi_sqrt(v); }
         else if (e.pc == 4) { v = cbrt(v); }
         else if (e.pc == 5) { v = pow(v, (T)e.p); }
     }

@@ -19,6 +19,8 @@
 // the stores).  Frames are dealt round-robin inside 8 contiguous ranges (one per group of
 // workgroups that share an XCD), so the 3/4 of a frame that overlaps its neighbours is served by
 // that XCD's L2 and every sample is fetched from HBM once.
+#include <mutex>
+#include <type_traits>
 #include "stft_common.h"
 #include "fft16.h"
 #include <cstdlib>
@@ -34,7 +36,15 @@ struct R4096Args {
     int L, W, stp, edge;
     Epilogue epi;
     int frames;           // B * W
+    int B;                // signals
+    unsigned *take;       // run form: 8 counters (one per blockIdx % 8), zero at launch
 };
+
+// Counters of the run form: R4096_SLOTS sets of 8, used in turn by successive launches on a device and
+// cleared in the launch's stream just before it.  Launches that overlap on one device share a set only
+// if R4096_SLOTS others were started in between.
+constexpr int R4096_SLOTS = 64;
+__device__ unsigned g_r4096_take[R4096_SLOTS * 8];
 
 constexpr int R4096_PITCH = 33;                         // complex slots per exchange row
 constexpr int R4096_WAVE_C = 64 * R4096_PITCH;          // complex slots per wave (>= 2048)
@@ -57,6 +67,12 @@ typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));   // 16-
 #endif
 #ifndef R4096_INTERLEAVE
 #define R4096_INTERLEAVE 1         // 1: twiddle products of four rows are issued before the fmas that consume them
+#endif
+#ifndef R4096_ALT_PRIO
+#define R4096_ALT_PRIO 0
+#endif
+#ifndef R4096_RUN
+#define R4096_RUN 16            // frames per run of the run form
 #endif
 #ifndef R4096_STAMPS
 #define R4096_STAMPS 0          // diagnostic builds: 1 = per-phase s_memtime sums into g_r4096_stamps
@@ -103,7 +119,9 @@ __device__ __forceinline__ void dft32c(C2 (&e)[16], C2 (&o)[16])
 // itself, which spreads the two half-blocks a wave store touches over all banks
 __device__ __forceinline__ int zpos(int k) { return k ^ (((k >> 5) & 1) << 3); }
 
-template <bool FULL, bool MN0, bool EPI>
+template <int R> using rot = std::integral_constant<int, R>;
+
+template <bool FULL, bool MN0, bool EPI, bool RUN>
 __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *__restrict__ Y, const float *__restrict__ X,
                                                                          const float *__restrict__ win, const float *__restrict__ tw,
                                                                          const R4096Args a)
@@ -140,17 +158,39 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
     C2 owm[4];                                                            // -i W4096^(4 lane + c), for the split
 #pragma unroll
     for (int c = 0; c < 4; ++c) { owm[c] = C2{tw[2 * (4 * lane + c) + 1], -tw[2 * (4 * lane + c)]}; }
+    // RUN keeps a frame's raw samples in registers; the twiddles that depend on the lane alone and are
+    // used once per frame (ta, owm) then live in LDS, behind the tiles, and are read where they are used
+    C2 *twl = reinterpret_cast<C2 *>(wtab + 4096) + R4096_WAVES * R4096_WAVE_C;   // owm at [4 lane + c], ta[q] at [256 + 64 q + lane]
+    if (RUN && wv == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { twl[4 * lane + c] = owm[c]; }
+#pragma unroll
+        for (int q = 1; q < 8; ++q) { twl[256 + 64 * q + lane] = ta[q]; }
+    }
     __syncthreads();
 
-    // frames: 8 contiguous ranges by blockIdx % 8, round-robin over the waves inside a range
+    // Work distribution, two forms.
+    // Runs (RUN: full window, uniform hop of 1024 = a quarter of the frame): a wave takes runs of
+    // R4096_RUN consecutive frames of one signal and reads it as a stream of groups of 1024 samples:
+    // frame t of the run is groups t .. t + 3, and group g lives in the registers pre[4 (g % 4) ..].
+    // Once the window step of frame t has read them, the 4 wave loads of group t + 4 go out into the
+    // registers of group t, a whole frame before they are waited for.  The registers thus hold frame t
+    // rotated by t % 4 quarters; the window is applied with the same rotation and the transform is taken
+    // of the rotated frame, whose power spectrum is that of the frame itself (a circular shift by a
+    // quarter of the length multiplies bin k by i^k).  Every sample is loaded once, no register moves,
+    // and nothing depends on the L2 holding a neighbour's lines.
+    // The runs are cut into 8 contiguous ranges by blockIdx % 8 and dealt round-robin inside a range.
+    // Frames (otherwise): 8 ranges of frames, static round-robin; the 8 waves of a workgroup take 8
+    // neighbouring frames per round and meet at a barrier every other round: without it they drift apart
+    // by more rounds than the L2 holds, the 3/4 of its samples that a frame shares with its neighbours
+    // miss, and 2.6x the samples come from HBM (measured with FETCH_SIZE).
     const int xcd = blockIdx.x & 7, nwg_x = gridDim.x >> 3;
-    const int f_lo = (int)((long long)a.frames * xcd / 8), f_hi = (int)((long long)a.frames * (xcd + 1) / 8);
+    constexpr int RL = R4096_RUN;                          // frames per run
+    const int rps = (a.W + RL - 1) / RL;                   // runs per signal
+    const int units = RUN ? a.B * rps : a.frames;
+    const int f_lo = (int)((long long)units * xcd / 8), f_hi = (int)((long long)units * (xcd + 1) / 8);
     const int fstride = nwg_x * R4096_WAVES;
-    // Static round-robin inside the range.  The 8 waves of a workgroup take 8 neighbouring frames per
-    // round and meet at a barrier every other round (below): without it they drift apart by more
-    // rounds than the L2 holds, the 3/4 of its samples that a frame shares with its neighbours miss,
-    // and 2.6x the samples come from HBM (measured with FETCH_SIZE).
-    int fid = f_lo + (blockIdx.x >> 3) * R4096_WAVES + wv;
+    int fid = f_lo + (blockIdx.x >> 3) * R4096_WAVES + wv;   // the wave's current frame, or (first) run
     int nfid = fid + fstride;
     if (fid >= f_hi) { return; }
 
@@ -171,7 +211,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
     C2 ze[16], zo[16];      // loads: columns 2 l4 (ze) and 2 l4 + 1 (zo), rows 2 i + up; later: the two halves of a 32-point transform
     // The first NE of a frame's 16 loads are issued a whole pass earlier than the rest, into registers of
     // their own (the transform registers are still busy then); the window step reads them from there.
-    constexpr int NE = R4096_EARLY;
+    constexpr int NE = RUN ? 16 : R4096_EARLY;             // RUN: the 16 rows of the frame
     float4 pre[NE > 0 ? NE : 1];
     const int loff = 128 * up + 4 * l4;                     // first sample of the lane inside a frame; row i adds 256
     // raw samples of a frame that lies inside its signal: 16 coalesced 1-KiB wave loads
@@ -206,27 +246,92 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         asm volatile("" ::: "memory");                 // keeps these LDS reads from being merged with load_inside's into flat loads
     };
 
-    Where cur = locate(fid);
-    if (cur.inside) { load_inside(cur, 0, 16); } else { load_edge(cur); }
+    // RUN: the current run (signal, first frame, frames) and the frame inside it
+    int run_b = 0, run_w0 = 0, run_len = 0, tpos = 0;
+    auto open_run = [&](int r) {
+        run_b = r / rps;
+        run_w0 = (r - run_b * rps) * RL;
+        run_len = min(RL, a.W - run_w0);
+    };
+    // Group g of the run (b, w0): where its 1024 samples lie.  A group that crosses an edge of the
+    // signal is gathered sample by sample into the tile first, which is idle at the call sites.
+    struct Group { const float *src; bool inside; };
+    auto find_group = [&](int b, int w0, int g) {
+        const float *xb = X + (long long)b * a.ldx;
+        const long long ssg = a.ss0 + (long long)w0 * a.stp + 1024LL * g;
+        const long long rdoff = a.edge ? a.rd_shift : 0;
+        Group q;
+        q.inside = ssg >= 0 && ssg + 1024 <= a.N && ssg >= rdoff;
+        q.src = xb + (ssg - rdoff) + loff;
+        if (!q.inside) {
+            FrameDesc d{};
+            d.N = a.N; d.edge = a.edge;
+            float *stage = reinterpret_cast<float *>(ex);
+            wave_sync();
+            for (int l = lane; l < 1024; l += 64) { stage[l] = fetch_sample(xb, d, ssg, rdoff, l); }
+            wave_sync();
+        }
+        return q;
+    };
+    // ... and into the registers of group slot j: 4 coalesced 1-KiB wave loads (or the staged copy)
+    auto fetch_group = [&](const Group &q, const int j) {
+        if (q.inside) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float4_u v = *reinterpret_cast<const float4_u *>(q.src + 256 * r);
+                pre[4 * j + r] = make_float4(v.x, v.y, v.z, v.w);
+            }
+        } else {
+            const float *stage = reinterpret_cast<const float *>(ex);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { pre[4 * j + r] = *reinterpret_cast<const float4 *>(stage + loff + 256 * r); }
+            asm volatile("" ::: "memory");
+        }
+    };
+    // the first frame of run r
+    auto load_run_head = [&](int r) {
+        const int b = r / rps, w0 = (r - b * rps) * RL;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { fetch_group(find_group(b, w0, g), g); }
+    };
+
+    Where cur{};
+    if constexpr (!RUN) {
+        cur = locate(fid);
+        if (cur.inside) { load_inside(cur, 0, 16); } else { load_edge(cur); }
+    }
 #if R4096_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory");
 #endif
 
     // One frame: transform the samples in the registers, start the next frame's loads, write the row.
-    // Returns false after the last frame.  The first frame runs in a copy of its own, so that inside
+    // Returns false after the last frame (RUN: of the run).  The first frame runs in a copy of its own, so that inside
     // the loop every wait on the prefetched samples sees the same sequence of loads followed by this
     // frame's stores and lets the stores drain in the background.
     int iter = 0;
-    auto frame = [&]() __attribute__((always_inline)) -> bool {
+    auto frame = [&](auto rot_c) __attribute__((always_inline)) -> bool {
+        constexpr int ROT = decltype(rot_c)::value;          // RUN: tpos % 4, the rotation of the frame in the registers
+#if R4096_ALT_PRIO
+        if constexpr (RUN) {
+            // The two waves of a SIMD are arbitrated oldest first: left alone, waves 0-3 of the workgroup
+            // run 40 % faster than waves 4-7 and finish their (equal) share early.  Alternating the
+            // priority frame by frame gives both the same pace.
+            if (wv >> 2) { __builtin_amdgcn_s_setprio(1 - (ROT & 1)); } else { __builtin_amdgcn_s_setprio(ROT & 1); }
+        }
+#endif
         // ---------------- pass 1: window, 32-point FFT over n1 ----------------
         {
             C2 acc = C2{0.f, 0.f};
             int lim = L - loff;                              // sample l = 256 i + loff + c is inside the window iff 256 i + c < lim
             asm volatile("" : "+v"(lim));                    // recomputed per frame: hoisted lane masks would not fit in SGPRs
+            // RUN: register group j holds the quarter (j - tpos) % 4 of the frame
+            const float *wrow[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { wrow[j] = wtab + loff + 1024 * ((j - ROT) & 3); }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float4 hh = *reinterpret_cast<const float4 *>(wtab + loff + 256 * i);
+                const float4 hh = *reinterpret_cast<const float4 *>(wrow[i >> 2] + 256 * (i & 3));
                 if (i < NE) { ze[i] = C2{pre[i].x, pre[i].y}; zo[i] = C2{pre[i].z, pre[i].w}; }
                 if (!FULL) {                                 // keep data past the window out (0 * NaN)
                     ze[i].x = (256 * i < lim) ? ze[i].x : 0.f;
@@ -250,6 +355,22 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
                 }
             }
         }
+        if constexpr (RUN) {
+            // the windowed values are complete here: without this the products sink below the loads that
+            // follow, the old and the new samples are both live, and the frame no longer fits the registers
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { asm volatile("" : "+v"(ze[i]), "+v"(zo[i])); }
+        }
+        R4096_STAMP(6);
+        // RUN: the stream moves on by one group, whose loads go out now, into the registers of the
+        // group that the next frame no longer holds
+        if constexpr (RUN) {
+            if (tpos + 1 < run_len) {
+                const Group q = find_group(run_b, run_w0, tpos + 4);
+                fetch_group(q, ROT);
+            }
+        }
+        R4096_STAMP(7);
         // 16-point transforms over this half-wave's rows, for both columns; then the half-waves trade
         // one column each, so that a lane holds E (even rows) and O (odd rows) of column n2, and
         // X[k1] = E + W32^k1 O, X[k1 + 16] = E - W32^k1 O
@@ -284,12 +405,13 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
 #pragma unroll
             for (int bb = 1; bb < 4; ++bb) { *zp[bb] = cx_mul_second<float>(*zp[bb], tb[bb], t[bb]); }
             if (q) {
+                const C2 taq = RUN ? twl[256 + 64 * q + lane] : ta[q];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int bb = 0; bb < 4; ++bb) { t[bb] = cx_mul_first<float>(*zp[bb], ta[q]); }
+                for (int bb = 0; bb < 4; ++bb) { t[bb] = cx_mul_first<float>(*zp[bb], taq); }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int bb = 0; bb < 4; ++bb) { *zp[bb] = cx_mul_second<float>(*zp[bb], ta[q], t[bb]); }
+                for (int bb = 0; bb < 4; ++bb) { *zp[bb] = cx_mul_second<float>(*zp[bb], taq, t[bb]); }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -299,7 +421,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
             C2 &z = (k1 < 16) ? ze[slot16(k1)] : zo[slot16(k1 - 16)];
             const int q = k1 >> 2, bb = k1 & 3;
             if (bb) { z = cx_mul<float>(z, tb[bb]); }
-            if (q) { z = cx_mul<float>(z, ta[q]); }
+            if (q) { z = cx_mul<float>(z, RUN ? twl[256 + 64 * q + lane] : ta[q]); }
         }
 #endif
         // first radix-2 stage of the 64-point transforms over n2: columns n2 and n2 + 32 sit 16 lanes
@@ -322,13 +444,18 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         }
         wave_sync();
         // where the next frame lies; its first loads go out now, under pass 2
-        const bool more = nfid < f_hi;
-        const Where nxt = locate(more ? nfid : fid);
-
+        bool more;
+        Where nxt;
+        if constexpr (RUN) {
+            more = false; nxt = cur;
+        } else {
+            more = nfid < f_hi;
+            nxt = locate(more ? nfid : fid);
 #if R4096_LOCKSTEP
-        if ((iter++ & (R4096_LOCK_EVERY - 1)) == 0) { __builtin_amdgcn_s_barrier(); }   // the workgroup's 8 waves request neighbouring frames together
+            if ((iter++ & (R4096_LOCK_EVERY - 1)) == 0) { __builtin_amdgcn_s_barrier(); }   // the workgroup's 8 waves request neighbouring frames together
 #endif
-        if (NE > 0 && nxt.inside) { load_inside(nxt, 0, NE); }
+            if (NE > 0 && nxt.inside) { load_inside(nxt, 0, NE); }
+        }
         R4096_STAMP(1);
 
         // ---------------- pass 2: lane = row (k1, parity): 32-point FFT ----------------
@@ -351,14 +478,17 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         R4096_STAMP(3);
 
         // the registers are free from here on: start the next frame's loads under the split
-        if (nxt.inside) { load_inside(nxt, NE, 16); }
+        if (!RUN && nxt.inside) { load_inside(nxt, NE, 16); }
         R4096_STAMP(4);
 
         // ---------------- split + power + store: lane handles bins k = 4 lane + c + 256 m and 2048 - k ----------------
-        float *y = Y + cur.row * F;
+        float *y = Y + (RUN ? (long long)run_b * a.W + run_w0 + tpos : cur.row) * F;
         const C2 *zk = ex + zpos(4 * lane);                                // Z[k] at zk[256 m + c]
         const C2 *zq0 = ex + zpos(M - 4 * lane) - 768;                     // Z[2048 - 4 lane - 256 m] at zq0[256 (3 - m)]
         const C2 *zq4 = ex + zpos(M - 4 - 4 * lane) - 768;                 // Z[2048 - 4 lane - 256 m - 4 + i] at zq4[256 (3 - m) + i]
+        C2 ow4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { ow4[c] = RUN ? twl[4 * lane + c] : owm[c]; }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             float p[4], q[4];
@@ -371,7 +501,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
                 C2 B = cx_sub_conj<float>(z, zm);
                 // -i W4096^k B with W4096^k = W4096^(4 lane + c) W16^m
                 if (m > 0) { B = cx_mul<float>(B, W64C[8 * m], W64C[8 * m + 1]); }
-                const C2 Tw = cx_mul<float>(B, owm[c]);
+                const C2 Tw = cx_mul<float>(B, ow4[c]);
                 p[c] = cx_norm<float>(A + Tw); q[c] = cx_norm<float>(A - Tw);
                 if (EPI) { p[c] = power_epilogue(p[c], a.epi); q[c] = power_epilogue(q[c], a.epi); }
             }
@@ -385,28 +515,78 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
                 *reinterpret_cast<float4_u *>(y + M - 3 - k0) = float4_u{q[3], q[2], q[1], q[0]};
             }
         }
-        if (lane == 0) {
-            float p = 4.0f * cx_norm<float>(ex[1024]);     // bin 1024 pairs with itself (Z holds half values)
+        {
+            // bin 1024 pairs with itself (Z holds half values).  Every lane stores the same value to the
+            // same address: a store under `if (lane == 0)` sits behind a branch, the count of stores after
+            // the prefetch loads is then unknown at compile time, and the wait for the loads also waits
+            // for the first store of this row to complete.
+            float p = 4.0f * cx_norm<float>(ex[1024]);
             if (EPI) { p = power_epilogue(p, a.epi); }
+#if R4096_ABLATE & 1
+            asm volatile("" :: "v"(p));
+            if (a.N == -12345)
+#endif
             y[1024] = p;
         }
         R4096_STAMP(5);
-        if (!more) { return false; }
-        if (!nxt.inside) { load_edge(nxt); }
-        cur = nxt;
-        fid = nfid;
-        nfid += fstride;
+        if constexpr (RUN) {
+            if (tpos + 1 >= run_len) { return false; }
+            ++tpos;
+        } else {
+            if (!more) { return false; }
+            if (!nxt.inside) { load_edge(nxt); }
+            cur = nxt;
+            fid = nfid;
+            nfid += fstride;
+        }
         return true;
     };
 #if R4096_STAMPS
-    if (frame()) { while (frame()) { } }
+    if constexpr (RUN) {
+        for (; fid < f_hi;) {
+            // The wave's next run is the next one nobody has taken yet in this range (the waves of a SIMD
+            // do not run at the same pace: a static deal leaves the faster ones idle at the end).  Asked
+            // for before this run's loads, so that the wait for those covers the answer as well.
+            unsigned took = 0;
+            if (lane == 0) { took = __hip_atomic_fetch_add(a.take + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            open_run(fid);
+            load_run_head(fid);
+            asm volatile("" : "+v"(took) : "v"(pre[3].w), "v"(pre[7].w), "v"(pre[11].w), "v"(pre[15].w));
+            const int nrun = f_lo + fstride + (int)__builtin_amdgcn_readfirstlane(took);
+            tpos = 0;
+            while (frame(rot<0>{}) && frame(rot<1>{}) && frame(rot<2>{}) && frame(rot<3>{})) { }
+            fid = nrun;
+        }
+    } else {
+        if (frame(rot<0>{})) { while (frame(rot<0>{})) { } }
+    }
     if (lane == 0) {
         const int gw = blockIdx.x * R4096_WAVES + wv;
         if (gw < 2048) { for (int i = 0; i < 8; ++i) { g_r4096_stamps[gw * 8 + i] = st_acc[i]; } }
     }
 #else
-    if (!frame()) { return; }
-    while (frame()) { }
+    if constexpr (RUN) {
+        // Run by run: the first frame's samples (16 wave loads, waited for at once, so that the waits
+        // inside the loop count only the loop's own loads and stores), then its frames, four to a round:
+        // the rotation of a frame is then a constant of its copy of the code.
+        for (; fid < f_hi;) {
+            // The wave's next run is the next one nobody has taken yet in this range (the waves of a SIMD
+            // do not run at the same pace: a static deal leaves the faster ones idle at the end).  Asked
+            // for before this run's loads, so that the wait for those covers the answer as well.
+            unsigned took = 0;
+            if (lane == 0) { took = __hip_atomic_fetch_add(a.take + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            open_run(fid);
+            load_run_head(fid);
+            asm volatile("" : "+v"(took) : "v"(pre[3].w), "v"(pre[7].w), "v"(pre[11].w), "v"(pre[15].w));
+            const int nrun = f_lo + fstride + (int)__builtin_amdgcn_readfirstlane(took);
+            tpos = 0;
+            while (frame(rot<0>{}) && frame(rot<1>{}) && frame(rot<2>{}) && frame(rot<3>{})) { }
+            fid = nrun;
+        }
+    } else {
+        if (!frame(rot<0>{})) { return; }
+        while (frame(rot<0>{})) { }
+    }
 #endif
 }
 #if R4096_STAMPS
@@ -422,16 +602,33 @@ bool r4096_supported(const FrameDesc &d)
     return d.nfft == 4096 && d.L >= 1 && d.L <= 4096 && (long long)d.B * d.W < (1ll << 31) - 4096;
 }
 
-template <bool FULL, bool MN0, bool EPI>
+template <bool FULL, bool MN0, bool EPI, bool RUN>
 static hipError_t launch_r4096_inst(float *Y, const float *X, const float *win, const float *tw, const R4096Args &a, hipStream_t s)
 {
-    const size_t lds = 4096 * sizeof(float) + (size_t)R4096_WAVES * R4096_WAVE_C * sizeof(float2);
+    const size_t lds = 4096 * sizeof(float) + (size_t)R4096_WAVES * R4096_WAVE_C * sizeof(float2) + (RUN ? (256 + 64 * 8) * sizeof(float2) : 0);
     static LdsGrant grant;
-    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r4096_kernel<FULL, MN0, EPI>), lds, grant); e != hipSuccess) { return e; }
+    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r4096_kernel<FULL, MN0, EPI, RUN>), lds, grant); e != hipSuccess) { return e; }
     long long grid = ((long long)a.frames + R4096_WAVES - 1) / R4096_WAVES;
     if (grid > 256) { grid = 256; }                      // one 8-wave workgroup per CU (151 KB of LDS each)
     grid = (grid + 7) & ~7ll;
-    hipLaunchKernelGGL((stft_r4096_kernel<FULL, MN0, EPI>), dim3((unsigned)grid), dim3(64 * R4096_WAVES), lds, s, Y, X, win, tw, a);
+    R4096Args b = a;
+    if (RUN) {
+        static std::mutex mu;
+        static unsigned *base[64];
+        static unsigned turn[64];
+        int dev = 0;
+        if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) { return e; }
+        if (dev < 0 || dev >= 64) { return hipErrorInvalidDevice; }
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            if (!base[dev]) {
+                if (hipError_t e = hipGetSymbolAddress(reinterpret_cast<void **>(&base[dev]), HIP_SYMBOL(g_r4096_take)); e != hipSuccess) { return e; }
+            }
+            b.take = base[dev] + 8 * (turn[dev]++ % R4096_SLOTS);
+        }
+        if (hipError_t e = hipMemsetAsync(b.take, 0, 8 * sizeof(unsigned), s); e != hipSuccess) { return e; }
+    }
+    hipLaunchKernelGGL((stft_r4096_kernel<FULL, MN0, EPI, RUN>), dim3((unsigned)grid), dim3(64 * R4096_WAVES), lds, s, Y, X, win, tw, b);
     return hipGetLastError();
 }
 
@@ -441,14 +638,25 @@ hipError_t launch_stft_r4096(float *Y, const float *X, const float *win, const f
     a.ldx = d.ldx; a.N = d.N; a.ss0 = d.ss0; a.rd_shift = d.rd_shift; a.tbl = d.tbl;
     a.L = d.L; a.W = d.W; a.stp = d.stp; a.edge = d.edge; a.epi = d.epi;
     a.frames = d.B * d.W;
+    a.B = d.B;
     const bool full = d.L == 4096, epi = d.epi.any();
-#define DSP_R4096(F_, M_, E_) launch_r4096_inst<F_, M_, E_>(Y, X, win, tw, a, s)
-    if (full) {
-        if (d.mn0) { return epi ? DSP_R4096(true, true, true) : DSP_R4096(true, true, false); }
-        return epi ? DSP_R4096(true, false, true) : DSP_R4096(true, false, false);
+    // the run form: full window, frames at ss0 + w * 1024
+    // ... where there are at least DSP_R4096_MIN_RUNS runs (default: two per wave of a full grid; 0 = never)
+    long long min_runs = 2 * 256 * R4096_WAVES;
+    if (const char *e = getenv("DSP_R4096_MIN_RUNS")) { min_runs = atoll(e) > 0 ? atoll(e) : (1ll << 62); }
+    const long long runs = (long long)d.B * ((d.W + R4096_RUN - 1) / R4096_RUN);
+    const bool run = full && d.tbl == nullptr && d.stp == 1024 && runs >= min_runs;
+#define DSP_R4096(F_, M_, E_, R_) launch_r4096_inst<F_, M_, E_, R_>(Y, X, win, tw, a, s)
+    if (run) {
+        if (d.mn0) { return epi ? DSP_R4096(true, true, true, true) : DSP_R4096(true, true, false, true); }
+        return epi ? DSP_R4096(true, false, true, true) : DSP_R4096(true, false, false, true);
     }
-    if (d.mn0) { return epi ? DSP_R4096(false, true, true) : DSP_R4096(false, true, false); }
-    return epi ? DSP_R4096(false, false, true) : DSP_R4096(false, false, false);
+    if (full) {
+        if (d.mn0) { return epi ? DSP_R4096(true, true, true, false) : DSP_R4096(true, true, false, false); }
+        return epi ? DSP_R4096(true, false, true, false) : DSP_R4096(true, false, false, false);
+    }
+    if (d.mn0) { return epi ? DSP_R4096(false, true, true, false) : DSP_R4096(false, true, false, false); }
+    return epi ? DSP_R4096(false, false, true, false) : DSP_R4096(false, false, false, false);
 #undef DSP_R4096
 }
 

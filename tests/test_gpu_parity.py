@@ -154,6 +154,31 @@ def test_both_4096_families_agree_with_oracle(O, D):
             D.set_flt_mode(False)
 
 
+def test_4096_run_form_agrees_with_oracle(O, D, monkeypatch):
+    """Full window with hop 1024: large inputs are transformed in runs of 16 consecutive frames per wave
+    (each sample loaded once, the frame held rotated in registers).  Forced here at small sizes: runs
+    that cross either edge of the signal, a last run shorter than 16, a signal shorter than one run,
+    several signals, every flag; then the frame form on the same input."""
+    import torch
+    dt = np.float32
+    win = D.blackmanharris(4096, dt)
+    for (N, flags) in [(40000, (0, 0, 0)), (16 * 1024 * 3 + 700, (1, 0, 0)), (100000, (0, 1, 1)), (5000, (1, 1, 0)), (4096 + 1024 * 31, (0, 0, 1))]:
+        x = signal(N, N, dt) + dt(0.2)
+        for snip in (0, 1):
+            rc, Yref = O.stft(x.astype(np.float64), win.astype(np.float64), 1024, 4096, snip, *flags, exact=False)
+            assert rc == 0
+            for min_runs in ("1", "0"):
+                monkeypatch.setenv("DSP_R4096_MIN_RUNS", min_runs)
+                Y = D.stft(x, win, 1024, bool(snip), *[bool(f) for f in flags], nfft=4096)
+                check_spec(O, Y, Yref.astype(dt), flags[1], flags[2])
+    monkeypatch.setenv("DSP_R4096_MIN_RUNS", "1")
+    xb = np.stack([signal(s, 70000, dt) for s in (1, 2, 3)])
+    Yb = D.stft_dev(torch.from_numpy(xb).cuda(), torch.from_numpy(win).cuda(), 1024).cpu().numpy()
+    for b in range(3):
+        rc, Yref = O.stft(xb[b].astype(np.float64), win.astype(np.float64), 1024, 4096, exact=False)
+        check_spec(O, Yb[b], Yref.astype(dt))
+
+
 @pytest.mark.parametrize("tag", ["s", "d"])
 def test_stft_against_reference_fixtures(O, D, tag):
     """Fixtures hold what the reference's own frame_univar -> apply_win -> FFT -> fft_power returned."""

@@ -68,6 +68,9 @@ template <> struct vec16<double> { using type = double2; static constexpr int n 
 #else
 #define R512F_ST(ptr, val) (*(ptr) = (val))
 #endif
+#ifndef R512F_ALT_PRIO
+#define R512F_ALT_PRIO 1        // 1 = the two workgroups of a CU swap issue priority every step
+#endif
 #ifndef R512F_STAMPS
 #define R512F_STAMPS 0          // diagnostic builds: 1 = per-phase s_memtime sums into g_r512f_stamps
 #endif
@@ -248,6 +251,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
     while (true) {
 #if R512F_LOCK_EVERY
         if ((it++ & (R512F_LOCK_EVERY - 1)) == 0) { __builtin_amdgcn_s_barrier(); }
+#if R512F_ALT_PRIO
+        // The two workgroups of a CU (blockIdx b and b + 256) share its SIMDs, and of two waves on a
+        // SIMD the older one issues first: left alone, one workgroup runs 5 % ahead of the other and
+        // the CU is half empty at the end.  Swapping the priority every step keeps them level.
+        if ((((int)blockIdx.x >> 8) ^ it) & 1) { __builtin_amdgcn_s_setprio(1); } else { __builtin_amdgcn_s_setprio(0); }
+#endif
 #endif
         // ---- pass 1: lane (frame f, column n2 = j): 16-point FFT over the rows n1 ----
         C zz[16];

@@ -48,6 +48,16 @@ SIGNATURES = {
     "povey_s": (_int, [_vp, _sz, _sz]), "povey_d": (_int, [_vp, _sz, _sz]),
     "blackmanharris_s": (_int, [_vp, _sz, _sz]), "blackmanharris_d": (_int, [_vp, _sz, _sz]),
     "dsp_window_dev_s": (_int, [_vp, _int, _sz, _sz, _vp]), "dsp_window_dev_d": (_int, [_vp, _int, _sz, _sz, _vp]),
+    "dsp_window_par_dev_s": (_int, [_vp, _int, _sz, _f, _int, _sz, _vp]), "dsp_window_par_dev_d": (_int, [_vp, _int, _sz, _d, _int, _sz, _vp]),
+    "blackman_s": (_int, [_vp, _sz, _int, _sz]), "blackman_d": (_int, [_vp, _sz, _int, _sz]),
+    "bartlett_s": (_int, [_vp, _sz, _sz]), "bartlett_d": (_int, [_vp, _sz, _sz]),
+    "triangular_s": (_int, [_vp, _sz, _sz]), "triangular_d": (_int, [_vp, _sz, _sz]),
+    "rectangular_s": (_int, [_vp, _sz, _sz]), "rectangular_d": (_int, [_vp, _sz, _sz]),
+    "flattop_s": (_int, [_vp, _sz, _sz]), "flattop_d": (_int, [_vp, _sz, _sz]),
+    "gauss_s": (_int, [_vp, _sz, _f, _sz]), "gauss_d": (_int, [_vp, _sz, _d, _sz]),
+    "tukey_s": (_int, [_vp, _sz, _f, _sz]), "tukey_d": (_int, [_vp, _sz, _d, _sz]),
+    "planck_s": (_int, [_vp, _sz, _f, _sz]), "planck_d": (_int, [_vp, _sz, _d, _sz]),
+    "convert_freqs_s": (_int, [_vp, _sz, C.c_char_p, C.c_char_p]), "convert_freqs_d": (_int, [_vp, _sz, C.c_char_p, C.c_char_p]),
     "pow_compress_s": (_int, [_vp, _vp, _sz, _f, _f]), "pow_compress_d": (_int, [_vp, _vp, _sz, _d, _d]),
     "pow_compress_inplace_s": (_int, [_vp, _sz, _f, _f]), "pow_compress_inplace_d": (_int, [_vp, _sz, _d, _d]),
     "get_stft_freqs_s": (_int, [_vp, _sz, _sz, _f]), "get_stft_freqs_d": (_int, [_vp, _sz, _sz, _d]),

@@ -212,30 +212,49 @@ def window_univar_flt(x, win, W, c0, stp):
     return Y
 
 
-WINDOW_IDS = {"hann": 0, "hamming": 1, "povey": 2, "blackmanharris": 3}
+WINDOW_IDS = {"hann": 0, "hamming": 1, "povey": 2, "blackmanharris": 3, "blackman": 4, "bartlett": 5, "triangular": 6,
+              "rectangular": 7, "flattop": 8, "gauss": 9, "tukey": 10, "planck": 11}
+WINDOW_PAR = {"gauss": 2.5, "tukey": 0.5, "planck": 0.1}        # generators with a parameter, and its default
 
 
-def window(name, L, norm=0, dtype=np.float32):
-    """hann_s/_d, hamming_s/_d, povey_s/_d, blackmanharris_s/_d: the window computed by the library."""
+def window(name, L, norm=0, dtype=np.float32, par=None, exact=False):
+    """hann_s/_d ... planck_s/_d: the window computed by the library.  par: gauss a, tukey r, planck
+    epsilon; exact: blackman's exact coefficients."""
     if name not in WINDOW_IDS:
         raise ValueError(f"unknown window {name}")
     s = _real_sfx(np.dtype(dtype))
     Y = np.empty(L, dtype=dtype)
-    rc = getattr(lib(), f"{name}_{s}")(_p(Y), L, norm)
+    fn = getattr(lib(), f"{name}_{s}")
+    if name in WINDOW_PAR:
+        rc = fn(_p(Y), L, float(WINDOW_PAR[name] if par is None else par), norm)
+    elif name == "blackman":
+        rc = fn(_p(Y), L, int(bool(exact)), norm)
+    else:
+        rc = fn(_p(Y), L, norm)
     _check(rc, f"{name}_{s}")
     return Y
 
 
-def window_dev(name, L, norm=0, dtype=None, device="cuda"):
-    """dsp_window_dev_s/_d: the window as a device tensor, enqueued on torch's current stream."""
+def window_dev(name, L, norm=0, dtype=None, device="cuda", par=None, exact=False):
+    """dsp_window_par_dev_s/_d: the window as a device tensor, enqueued on torch's current stream."""
     import torch
     dtype = torch.float32 if dtype is None else dtype
     out = torch.empty(L, dtype=dtype, device=device)
     s = _torch_sfx(out)
+    par = WINDOW_PAR.get(name, 0.0) if par is None else par
     with torch.cuda.device(out.device):
-        rc = getattr(lib(), f"dsp_window_dev_{s}")(C.c_void_p(out.data_ptr()), WINDOW_IDS[name], L, norm, _stream_ptr(out))
-    _check(rc, f"dsp_window_dev_{s}")
+        rc = getattr(lib(), f"dsp_window_par_dev_{s}")(C.c_void_p(out.data_ptr()), WINDOW_IDS[name], L, float(par), int(bool(exact)), norm, _stream_ptr(out))
+    _check(rc, f"dsp_window_par_dev_{s}")
     return out
+
+
+def convert_freqs(frqs, in_scale, out_scale):
+    """convert_freqs_s / _d: a copy of the frequency axis on another scale ("hz", "sqrt", "cbrt", "octave")."""
+    y = np.array(frqs, copy=True)
+    s = _real_sfx(y.dtype)
+    rc = getattr(lib(), f"convert_freqs_{s}")(_p(y), y.size, in_scale.encode(), out_scale.encode())
+    _check(rc, f"convert_freqs_{s}")
+    return y
 
 
 def pow_compress(x, p, preg=0.0, inplace=False):

@@ -409,9 +409,20 @@ int pow_compress_dev(const char *fn, T *Yd, const T *Xd, size_t N, T p, T preg, 
 
 // window generators: checks and message of reference c/hann.c:23
 template <typename T>
-int window_host(const char *fn, T *Y, size_t L, size_t norm, int kind)
+bool window_par_ok(const char *fn, int kind, T par)
+{
+    // reference c/gauss.c:20, c/tukey.c:24, c/planck.c:20
+    if (kind == WIN_GAUSS && !(par > T(0))) { fprintf(stderr, "error in %s: a must be positive \n", fn); return false; }
+    if (kind == WIN_TUKEY && !(par >= T(0) && par <= T(1))) { fprintf(stderr, "error in %s: r must be in [0.0 1.0] \n", fn); return false; }
+    if (kind == WIN_PLANCK && !(par >= T(0) && par <= T(0.5))) { fprintf(stderr, "error in %s: epsilon must be in [0.0 0.5] \n", fn); return false; }
+    return true;
+}
+
+template <typename T>
+int window_host(const char *fn, T *Y, size_t L, size_t norm, int kind, T par = T(0), int flag = 0)
 {
     if (norm > 3u) { fprintf(stderr, "error in %s: norm must be in {0,1,2,3}\n", fn); return 1; }
+    if (!window_par_ok<T>(fn, kind, par)) { return 1; }
     if (L > (size_t)INT_MAX / 4) { fprintf(stderr, "error in %s: problem size exceeds the supported index range\n", fn); return 1; }
     if (L == 0) { return 0; }
     int dev;
@@ -420,22 +431,23 @@ int window_host(const char *fn, T *Y, size_t L, size_t norm, int kind)
     std::lock_guard<std::mutex> lk(st.ws_mu);
     void *dy;
     if (ws_reserve(fn, st, 1, L * sizeof(T), dy)) { return 1; }
-    HIPCHK(fn, launch_window<T>((T *)dy, L, kind, (int)norm, nullptr));
+    HIPCHK(fn, launch_window<T>((T *)dy, L, kind, (int)norm, par, flag, nullptr));
     HIPCHK(fn, hipMemcpy(Y, dy, L * sizeof(T), hipMemcpyDeviceToHost));
     return 0;
 }
 
 template <typename T>
-int window_dev(const char *fn, T *Yd, int kind, size_t L, size_t norm, void *stream)
+int window_dev(const char *fn, T *Yd, int kind, size_t L, size_t norm, void *stream, T par = T(0), int flag = 0)
 {
-    if (kind < 0 || kind > 3) { fprintf(stderr, "error in %s: window must be 0 (hann), 1 (hamming), 2 (povey) or 3 (blackmanharris)\n", fn); return 1; }
+    if (kind < 0 || kind >= WIN_COUNT) { fprintf(stderr, "error in %s: window must be in 0..%d (hann, hamming, povey, blackmanharris, blackman, bartlett, triangular, rectangular, flattop, gauss, tukey, planck)\n", fn, WIN_COUNT - 1); return 1; }
     if (norm > 3u) { fprintf(stderr, "error in %s: norm must be in {0,1,2,3}\n", fn); return 1; }
+    if (!window_par_ok<T>(fn, kind, par)) { return 1; }
     if (L > (size_t)INT_MAX / 4) { fprintf(stderr, "error in %s: problem size exceeds the supported index range\n", fn); return 1; }
     if (L == 0) { return 0; }
     if (!Yd) { fprintf(stderr, "error in %s: null device pointer\n", fn); return 1; }
     int dev;
     if (use_device(fn, dev)) { return 1; }
-    HIPCHK(fn, launch_window<T>(Yd, L, kind, (int)norm, (hipStream_t)stream));
+    HIPCHK(fn, launch_window<T>(Yd, L, kind, (int)norm, par, flag, (hipStream_t)stream));
     return 0;
 }
 
@@ -450,6 +462,39 @@ int stft_freqs(const char *fn, T *Y, size_t nfft, size_t F, T fs)
     Y[0] = T(0);
     for (size_t f = 1; f < F && f < nyq; ++f) { Y[f] = (T)f * finc; }
     for (size_t f = nyq > 1 ? nyq : 1; f < F; ++f) { Y[f] = -finc * (T)(nfft - f); }
+    return 0;
+}
+
+// Frequency scales of the axis, in place on the host like the axis itself (reference
+// c/convert_freqs.c:24-127): hz, sqrt, cbrt, octave (log2).  The reference tells the input scale by its
+// first two characters ("octave": six) and the output scale by four ("hz": two, "octave": six).
+template <typename T>
+int convert_freqs_host(const char *fn, T *frqs, size_t F, const char *in_scale, const char *out_scale)
+{
+    if (!in_scale || strlen(in_scale) < 2u) { fprintf(stderr, "error in %s: input freq scale must be string with length > 1\n", fn); return 1; }
+    if (!out_scale || strlen(out_scale) < 2u) { fprintf(stderr, "error in %s: output freq scale must be string with length > 1\n", fn); return 1; }
+    if (F == 0u) { return 0; }
+    int in, out;
+    if (strncmp(in_scale, "hz", 2u) == 0) { in = 0; }
+    else if (strncmp(in_scale, "sq", 2u) == 0) { in = 1; }
+    else if (strncmp(in_scale, "cb", 2u) == 0) { in = 2; }
+    else if (strncmp(in_scale, "octave", 6u) == 0) { in = 3; }
+    else { fprintf(stderr, "error in %s: input frequency scale not recognized\n", fn); return 1; }
+    if (strncmp(out_scale, "hz", 2u) == 0) { out = 0; }
+    else if (strncmp(out_scale, "sqrt", 4u) == 0) { out = 1; }
+    else if (strncmp(out_scale, "cbrt", 4u) == 0) { out = 2; }
+    else if (strncmp(out_scale, "octave", 6u) == 0) { out = 3; }
+    else { fprintf(stderr, "error in %s: output frequency scale not recognized\n", fn); return 1; }
+    if (in == out) { return 0; }
+    for (size_t f = 0; f < F; ++f) {
+        const T x = frqs[f];
+        T y;
+        if (in == 0) { y = (out == 1) ? std::sqrt(x) : (out == 2) ? std::cbrt(x) : std::log2(x); }
+        else if (in == 1) { y = (out == 0) ? x * x : (out == 2) ? std::cbrt(x * x) : std::log2(x * x); }
+        else if (in == 2) { y = (out == 0) ? x * (x * x) : (out == 1) ? std::sqrt(x * x * x) : std::log2(x * x * x); }
+        else { y = (out == 0) ? std::pow(T(2), x) : (out == 1) ? std::pow(T(2), T(0.5) * x) : std::cbrt(std::pow(T(2), x)); }
+        frqs[f] = y;
+    }
     return 0;
 }
 
@@ -617,8 +662,28 @@ int povey_s(float *Y, const size_t L, const size_t norm) { return window_host<fl
 int povey_d(double *Y, const size_t L, const size_t norm) { return window_host<double>("povey_d", Y, L, norm, 2); }
 int blackmanharris_s(float *Y, const size_t L, const size_t norm) { return window_host<float>("blackmanharris_s", Y, L, norm, 3); }
 int blackmanharris_d(double *Y, const size_t L, const size_t norm) { return window_host<double>("blackmanharris_d", Y, L, norm, 3); }
-int dsp_window_dev_s(float *Y_dev, const int window, const size_t L, const size_t norm, void *stream) { return window_dev<float>("dsp_window_dev_s", Y_dev, window, L, norm, stream); }
-int dsp_window_dev_d(double *Y_dev, const int window, const size_t L, const size_t norm, void *stream) { return window_dev<double>("dsp_window_dev_d", Y_dev, window, L, norm, stream); }
+int blackman_s(float *Y, const size_t L, const int exact, const size_t norm) { return window_host<float>("blackman_s", Y, L, norm, WIN_BLACKMAN, 0.f, exact != 0); }
+int blackman_d(double *Y, const size_t L, const int exact, const size_t norm) { return window_host<double>("blackman_d", Y, L, norm, WIN_BLACKMAN, 0.0, exact != 0); }
+int bartlett_s(float *Y, const size_t L, const size_t norm) { return window_host<float>("bartlett_s", Y, L, norm, WIN_BARTLETT); }
+int bartlett_d(double *Y, const size_t L, const size_t norm) { return window_host<double>("bartlett_d", Y, L, norm, WIN_BARTLETT); }
+int triangular_s(float *Y, const size_t L, const size_t norm) { return window_host<float>("triangular_s", Y, L, norm, WIN_TRIANGULAR); }
+int triangular_d(double *Y, const size_t L, const size_t norm) { return window_host<double>("triangular_d", Y, L, norm, WIN_TRIANGULAR); }
+int rectangular_s(float *Y, const size_t L, const size_t norm) { return window_host<float>("rectangular_s", Y, L, norm, WIN_RECTANGULAR); }
+int rectangular_d(double *Y, const size_t L, const size_t norm) { return window_host<double>("rectangular_d", Y, L, norm, WIN_RECTANGULAR); }
+int flattop_s(float *Y, const size_t L, const size_t norm) { return window_host<float>("flattop_s", Y, L, norm, WIN_FLATTOP); }
+int flattop_d(double *Y, const size_t L, const size_t norm) { return window_host<double>("flattop_d", Y, L, norm, WIN_FLATTOP); }
+int gauss_s(float *Y, const size_t L, const float r, const size_t norm) { return window_host<float>("gauss_s", Y, L, norm, WIN_GAUSS, r); }
+int gauss_d(double *Y, const size_t L, const double r, const size_t norm) { return window_host<double>("gauss_d", Y, L, norm, WIN_GAUSS, r); }
+int tukey_s(float *Y, const size_t L, const float r, const size_t norm) { return window_host<float>("tukey_s", Y, L, norm, WIN_TUKEY, r); }
+int tukey_d(double *Y, const size_t L, const double r, const size_t norm) { return window_host<double>("tukey_d", Y, L, norm, WIN_TUKEY, r); }
+int planck_s(float *Y, const size_t L, const float epsilon, const size_t norm) { return window_host<float>("planck_s", Y, L, norm, WIN_PLANCK, epsilon); }
+int planck_d(double *Y, const size_t L, const double epsilon, const size_t norm) { return window_host<double>("planck_d", Y, L, norm, WIN_PLANCK, epsilon); }
+int dsp_window_dev_s(float *Y_dev, const int window, const size_t L, const size_t norm, void *stream) { return window_dev<float>("dsp_window_dev_s", Y_dev, window, L, norm, stream, window == WIN_GAUSS ? 2.5f : window == WIN_TUKEY ? 0.5f : window == WIN_PLANCK ? 0.1f : 0.f); }
+int dsp_window_dev_d(double *Y_dev, const int window, const size_t L, const size_t norm, void *stream) { return window_dev<double>("dsp_window_dev_d", Y_dev, window, L, norm, stream, window == WIN_GAUSS ? 2.5 : window == WIN_TUKEY ? 0.5 : window == WIN_PLANCK ? 0.1 : 0.0); }
+int dsp_window_par_dev_s(float *Y_dev, const int window, const size_t L, const float par, const int flag, const size_t norm, void *stream) { return window_dev<float>("dsp_window_par_dev_s", Y_dev, window, L, norm, stream, par, flag != 0); }
+int dsp_window_par_dev_d(double *Y_dev, const int window, const size_t L, const double par, const int flag, const size_t norm, void *stream) { return window_dev<double>("dsp_window_par_dev_d", Y_dev, window, L, norm, stream, par, flag != 0); }
+int convert_freqs_s(float *frqs, const size_t F, const char in_scale[], const char out_scale[]) { return convert_freqs_host<float>("convert_freqs_s", frqs, F, in_scale, out_scale); }
+int convert_freqs_d(double *frqs, const size_t F, const char in_scale[], const char out_scale[]) { return convert_freqs_host<double>("convert_freqs_d", frqs, F, in_scale, out_scale); }
 int pow_compress_s(float *Y, const float *X, const size_t N, const float p, const float preg) { return pow_compress_host<float>("pow_compress_s", Y, X, N, p, preg); }
 int pow_compress_d(double *Y, const double *X, const size_t N, const double p, const double preg) { return pow_compress_host<double>("pow_compress_d", Y, X, N, p, preg); }
 int pow_compress_inplace_s(float *X, const size_t N, const float p, const float preg) { return pow_compress_host<float>("pow_compress_inplace_s", X, X, N, p, preg); }

@@ -226,25 +226,55 @@ hipError_t launch_pow_compress(T *Y, const T *X, size_t N, const Epilogue &e, hi
 }
 
 // Window generators (reference c/hann.c:21-41, c/hamming.c:20-40, c/povey.c:21-41,
-// c/blackmanharris.c:22-42): symmetric windows of period L-1, first half from the formula in T
-// arithmetic, centre of an odd length forced to 1, second half mirrored; norm 1 divides by the sum,
-// 2 by the root of the sum of squares, 3 by the element L/2.  One workgroup; sums in double.
+// c/blackmanharris.c:22-42, c/blackman.c:26-54, c/bartlett.c:18-41, c/triangular.c:18-38,
+// c/rectangular.c:17-37, c/flattop.c:23-43, c/gauss.c:17-39, c/tukey.c:21-48, c/planck.c:17-45):
+// symmetric windows, first half from the formula in T arithmetic, centre of an odd length forced to 1
+// (tukey and planck: from the formula as well), second half mirrored; norm 1 divides by the sum (flattop:
+// of magnitudes), 2 by the root of the sum of squares, 3 by the element L/2.  par: gauss a, tukey r,
+// planck epsilon; flag: blackman "exact" coefficients.  One workgroup; sums in double.
 template <typename T>
-__global__ __launch_bounds__(256) void window_kernel(T *__restrict__ Y, const int L, const int kind, const int norm)
+__global__ __launch_bounds__(256) void window_kernel(T *__restrict__ Y, const int L, const int kind, const int norm, const T par, const int flag)
 {
     __shared__ double red[256];
-    const int tid = threadIdx.x, h = L / 2;
+    const int tid = threadIdx.x, h = L / 2, odd = L & 1;
+    const bool taper = kind == WIN_TUKEY || kind == WIN_PLANCK;      // the formula runs through the centre
     const T p = (T)(6.283185307179586476925286766559 / (double)(L - 1));
-    for (int l = tid; l < h; l += 256) {
+    // tukey: period of the cosine lobes and their length; planck: length of the tapers
+    const T pt = (kind == WIN_TUKEY) ? (T)(6.283185307179586476925286766559 / ((double)(L - 1) * (double)par)) : par * (T)L;
+    const int Lt = (kind == WIN_TUKEY) ? (int)ceil(T(0.5) * par * (T)L) : (int)ceil(pt);
+    for (int l = tid; l < h + (taper ? odd : 0); l += 256) {
         T v;
-        if (kind == 0) { v = T(0.5) - T(0.5) * cos((T)l * p); }
-        else if (kind == 1) { v = T(0.54) - T(0.46) * cos((T)l * p); }
-        else if (kind == 2) { v = pow(T(0.5) - T(0.5) * cos((T)l * p), T(0.85)); }
-        else { v = T(0.35875) - T(0.48829) * cos((T)l * p) + T(0.14128) * cos((T)(2 * l) * p) - T(0.01168) * cos((T)(3 * l) * p); }
+        const T c1 = cos((T)l * p);
+        switch (kind) {
+        case WIN_HANN: v = T(0.5) - T(0.5) * c1; break;
+        case WIN_HAMMING: v = T(0.54) - T(0.46) * c1; break;
+        case WIN_POVEY: v = pow(T(0.5) - T(0.5) * c1, T(0.85)); break;
+        case WIN_BLACKMANHARRIS: v = T(0.35875) - T(0.48829) * c1 + T(0.14128) * cos((T)(2 * l) * p) - T(0.01168) * cos((T)(3 * l) * p); break;
+        case WIN_BLACKMAN:
+            if (flag) { v = T(7938.0) / T(18608.0) - T(9240.0) / T(18608.0) * c1 + T(1430.0) / T(18608.0) * cos((T)(2 * l) * p); }
+            else { v = T(0.42) - T(0.5) * c1 + T(0.08) * cos((T)(2 * l) * p); }
+            break;
+        case WIN_BARTLETT: v = (T)(l * (2 - odd)) * (T(1) / (T)(L - odd * h - 1)); break;
+        case WIN_TRIANGULAR: v = (T)(l * (2 - odd) + 1) * (T(1) / (T)(L - odd * h)); break;
+        case WIN_RECTANGULAR: v = T(1); break;
+        case WIN_FLATTOP:
+            v = T(0.21557895) - T(0.41663158) * c1 + T(0.277263158) * cos((T)(2 * l) * p) - T(0.083578947) * cos((T)(3 * l) * p) + T(0.006947368) * cos((T)(4 * l) * p);
+            break;
+        case WIN_GAUSS: {
+            const T q = T(-2) * (par * par / (T)((long long)(L - 1) * (L - 1)));
+            const T m = T(0.5) * (T)(L - 1);
+            v = exp(((T)l - m) * ((T)l - m) * q);
+            break;
+        }
+        case WIN_TUKEY: v = (L <= 2 || l >= Lt) ? T(1) : T(0.5) - T(0.5) * cos((T)l * pt); break;
+        default:   // WIN_PLANCK
+            v = (L <= 2 || l >= Lt) ? T(1) : (l == 0 ? T(0) : T(1) / (T(1) + exp(pt / (T)l - pt / (pt - (T)l))));
+            break;
+        }
         Y[l] = v;
         Y[L - 1 - l] = v;
     }
-    if ((L & 1) && tid == 0) { Y[h] = T(1); }
+    if (odd && !taper && tid == 0) { Y[h] = T(1); }
     if (norm == 0) { return; }
     __syncthreads();
     double nrm;
@@ -252,7 +282,7 @@ __global__ __launch_bounds__(256) void window_kernel(T *__restrict__ Y, const in
         nrm = (double)Y[h];
     } else {
         double acc = 0.0;
-        for (int l = tid; l < L; l += 256) { const double v = (double)Y[l]; acc += (norm == 1) ? v : v * v; }
+        for (int l = tid; l < L; l += 256) { const double v = (double)Y[l]; acc += (norm == 1) ? (kind == WIN_FLATTOP ? fabs(v) : v) : v * v; }
         red[tid] = acc;
         __syncthreads();
         for (int o = 128; o > 0; o >>= 1) {
@@ -267,14 +297,14 @@ __global__ __launch_bounds__(256) void window_kernel(T *__restrict__ Y, const in
 }
 
 template <typename T>
-hipError_t launch_window(T *Y, size_t L, int kind, int norm, hipStream_t s)
+hipError_t launch_window(T *Y, size_t L, int kind, int norm, T par, int flag, hipStream_t s)
 {
     if (L == 0) { return hipSuccess; }
-    hipLaunchKernelGGL(window_kernel<T>, dim3(1), dim3(256), 0, s, Y, (int)L, kind, norm);
+    hipLaunchKernelGGL(window_kernel<T>, dim3(1), dim3(256), 0, s, Y, (int)L, kind, norm, par, flag);
     return hipGetLastError();
 }
-template hipError_t launch_window<float>(float *, size_t, int, int, hipStream_t);
-template hipError_t launch_window<double>(double *, size_t, int, int, hipStream_t);
+template hipError_t launch_window<float>(float *, size_t, int, int, float, int, hipStream_t);
+template hipError_t launch_window<double>(double *, size_t, int, int, double, int, hipStream_t);
 
 // reference c/frame_univar.c:41-95, c/frame_univar_flt.c:29-91 -- Y[w][l] = X[index(w,l)], E values
 // of T per sample (1 real, 2 complex)

@@ -126,7 +126,9 @@ hipError_t launch_stft_r4096(float *Y, const float *X, const float *win, const f
 template <typename T> hipError_t launch_stft_r512_fast(T *Y, const T *X, const T *win, const T *tw, const FrameDesc &d, hipStream_t s);
 
 // ---- unfused kernels (unfused_kernels.hip) ----------------------------------------------------
-template <typename T> hipError_t launch_window(T *Y, size_t L, int kind, int norm, hipStream_t s);
+enum WindowKind { WIN_HANN = 0, WIN_HAMMING, WIN_POVEY, WIN_BLACKMANHARRIS, WIN_BLACKMAN, WIN_BARTLETT, WIN_TRIANGULAR,
+                  WIN_RECTANGULAR, WIN_FLATTOP, WIN_GAUSS, WIN_TUKEY, WIN_PLANCK, WIN_COUNT };
+template <typename T> hipError_t launch_window(T *Y, size_t L, int kind, int norm, T par, int flag, hipStream_t s);
 template <typename T> hipError_t launch_fft_power(T *Y, const T *X, size_t N, hipStream_t s);
 template <typename T> hipError_t launch_pow_compress(T *Y, const T *X, size_t N, const Epilogue &e, hipStream_t s);
 // win != nullptr (E == 1 only): every frame is multiplied by the L window values

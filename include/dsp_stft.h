@@ -93,6 +93,29 @@ int povey_s (float *Y, const size_t L, const size_t norm);
 int povey_d (double *Y, const size_t L, const size_t norm);
 int blackmanharris_s (float *Y, const size_t L, const size_t norm);
 int blackmanharris_d (double *Y, const size_t L, const size_t norm);
+/* reference c/blackman.c:20-21 (exact != 0: the coefficients 7938, 9240, 1430 over 18608),
+ * c/bartlett.c:12-13, c/triangular.c:12-13, c/rectangular.c:11-12, c/flattop.c:17-18 (norm 1: sum of
+ * magnitudes), c/gauss.c:11-12 (exp(-2 (a (l - (L-1)/2) / (L-1))^2), a > 0), c/tukey.c:15-16 (cosine
+ * lobes over ceil(r L / 2) values at each end, r in [0,1]), c/planck.c:11-12 (Planck tapers over
+ * ceil(epsilon L) values, epsilon in [0,0.5]).  Two cases in which the reference writes outside the
+ * L values or leaves one unwritten are defined here: planck with epsilon 0 is all ones, and with an
+ * odd L and ceil(epsilon L) > L/2 the centre value comes from the taper formula. */
+int blackman_s (float *Y, const size_t L, const int exact, const size_t norm);
+int blackman_d (double *Y, const size_t L, const int exact, const size_t norm);
+int bartlett_s (float *Y, const size_t L, const size_t norm);
+int bartlett_d (double *Y, const size_t L, const size_t norm);
+int triangular_s (float *Y, const size_t L, const size_t norm);
+int triangular_d (double *Y, const size_t L, const size_t norm);
+int rectangular_s (float *Y, const size_t L, const size_t norm);
+int rectangular_d (double *Y, const size_t L, const size_t norm);
+int flattop_s (float *Y, const size_t L, const size_t norm);
+int flattop_d (double *Y, const size_t L, const size_t norm);
+int gauss_s (float *Y, const size_t L, const float r, const size_t norm);
+int gauss_d (double *Y, const size_t L, const double r, const size_t norm);
+int tukey_s (float *Y, const size_t L, const float r, const size_t norm);
+int tukey_d (double *Y, const size_t L, const double r, const size_t norm);
+int planck_s (float *Y, const size_t L, const float epsilon, const size_t norm);
+int planck_d (double *Y, const size_t L, const double epsilon, const size_t norm);
 
 /* reference c/pow_compress.c:17-20.  Y[n] = f(X[n] + preg) over N values: p == 1 identity, p == 0
  * natural log, p == 0.5 sqrt, |p - 1/3| <= FLT_EPSILON cbrt, otherwise pow(., p); p in [0,1],
@@ -107,6 +130,10 @@ int pow_compress_inplace_d (double *X, const size_t N, const double p, const dou
  * the host (metadata, not part of the transform). */
 int get_stft_freqs_s (float *Y, const size_t nfft, const size_t F, const float fs);
 int get_stft_freqs_d (double *Y, const size_t nfft, const size_t F, const double fs);
+/* reference c/convert_freqs.c:14-15.  The F values of a frequency axis, in place, from one scale to
+ * another: "hz", "sqrt", "cbrt", "octave" (log2).  Host array, computed on the host like the axis. */
+int convert_freqs_s (float *frqs, const size_t F, const char in_scale[], const char out_scale[]);
+int convert_freqs_d (double *frqs, const size_t F, const char in_scale[], const char out_scale[]);
 
 
 /* ===================== Part 2: additions (no counterpart in the reference) ===================== */
@@ -150,9 +177,14 @@ int dsp_pow_compress_dev_s (float *Y_dev, const float *X_dev, const size_t N, co
 int dsp_pow_compress_dev_d (double *Y_dev, const double *X_dev, const size_t N, const double p, const double preg, void *stream);
 
 /* Window generated straight into device memory (window: 0 hann, 1 hamming, 2 povey,
- * 3 blackmanharris), enqueued on `stream`: the X2 of the *_dev entry points without a host array. */
+ * 3 blackmanharris, 4 blackman, 5 bartlett, 6 triangular, 7 rectangular, 8 flattop, 9 gauss, 10 tukey,
+ * 11 planck), enqueued on `stream`: the X2 of the *_dev entry points without a host array.  The _par
+ * form takes the generator's parameter (gauss a, tukey r, planck epsilon) and flag (blackman exact);
+ * the plain form uses a = 2.5, r = 0.5, epsilon = 0.1, exact = 0. */
 int dsp_window_dev_s (float *Y_dev, const int window, const size_t L, const size_t norm, void *stream);
 int dsp_window_dev_d (double *Y_dev, const int window, const size_t L, const size_t norm, void *stream);
+int dsp_window_par_dev_s (float *Y_dev, const int window, const size_t L, const float par, const int flag, const size_t norm, void *stream);
+int dsp_window_par_dev_d (double *Y_dev, const int window, const size_t L, const double par, const int flag, const size_t norm, void *stream);
 
 /* Device-resident fft_power over N interleaved complex values, enqueued on `stream`. */
 int dsp_fft_power_dev_c (float *Y_dev, const float *X_dev, const size_t N, void *stream);

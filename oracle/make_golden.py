@@ -107,6 +107,35 @@ def main():
         d["blackmanharris.4096"] = O.ref_window("blackmanharris", 4096, dt)
         np.savez_compressed(os.path.join(OUT, f"ref_windows_{tag}.npz"), **d)
 
+        # the other generators: keys name.L.nK, parameter variants name@par.L.nK, blackman exact: blackman@1
+        d = {}
+        variants = [("blackman", None, 0), ("blackman", None, 1), ("bartlett", None, 0), ("triangular", None, 0),
+                    ("rectangular", None, 0), ("flattop", None, 0), ("gauss", 2.5, 0), ("gauss", 0.7, 0),
+                    ("tukey", 0.5, 0), ("tukey", 0.0, 0), ("tukey", 1.0, 0), ("tukey", 0.37, 0),
+                    ("planck", 0.1, 0), ("planck", 0.25, 0), ("planck", 0.45, 0)]
+        for wname, par, exact in variants:
+            tagname = wname + (f"@{par}" if par is not None else ("@1" if exact else ""))
+            for L in (1, 2, 3, 7, 8, 400, 401):
+                if wname == "planck" and L % 2 and int(np.ceil(par * L)) > L // 2:
+                    continue                       # the reference leaves the centre unwritten there
+                for norm in ((0, 1, 2, 3) if L in (7, 400, 401) else (0,)):
+                    d[f"{tagname}.{L}.n{norm}"] = O.ref_window(wname, L, dt, norm, par, exact)
+        np.savez_compressed(os.path.join(OUT, f"ref_windows2_{tag}.npz"), **d)
+
+        d = {}
+        hz = O.get_stft_freqs(512, 257, 16000.0, dt, use_ref=True)[1][1:]
+        scales = ("hz", "sqrt", "cbrt", "octave")
+        d["hz"] = hz
+        for a in scales:
+            rc, xa = O.ref_convert_freqs(hz, "hz", a)
+            assert rc == 0
+            for b in scales:
+                rc, y = O.ref_convert_freqs(xa, a, b)
+                assert rc == 0
+                d[f"{a}.{b}"] = y
+            d[f"in.{a}"] = xa
+        np.savez_compressed(os.path.join(OUT, f"ref_convert_freqs_{tag}.npz"), **d)
+
         # complex framing / windowing (frame_univar_c/z, frame_univar_flt_c/z, apply_win_c/z in place form)
         d = {}
         rng = np.random.default_rng(5)

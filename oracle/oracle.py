@@ -291,15 +291,34 @@ def get_stft_freqs(nfft, F, fs, dtype, use_ref=False):
     return rc, Y
 
 
-def ref_window(name, L, dtype, norm=0):
-    """reference window generators c/hann.c, c/hamming.c, c/povey.c, c/blackmanharris.c."""
+def ref_window(name, L, dtype, norm=0, par=None, exact=0):
+    """reference window generators c/hann.c, c/hamming.c, c/povey.c, c/blackmanharris.c, c/blackman.c
+    (exact), c/bartlett.c, c/triangular.c, c/rectangular.c, c/flattop.c, c/gauss.c, c/tukey.c, c/planck.c
+    (par).  The output buffer carries a guard element on each side, which must come back untouched."""
     s, _ = _sfx(dtype)
-    Y = np.zeros(L, dtype=dtype)
+    buf = np.full(L + 2, 77.0, dtype=dtype)
+    Y = buf[1:L + 1]
     f = getattr(ref(), f"{name}_{s}")
     f.restype = _int
-    rc = f(_ptr(Y), _sz(L), _sz(norm))
+    if name in ("gauss", "tukey", "planck"):
+        rc = f(_ptr(Y), _sz(L), (C.c_float if s == "s" else C.c_double)(par), _sz(norm))
+    elif name == "blackman":
+        rc = f(_ptr(Y), _sz(L), _int(exact), _sz(norm))
+    else:
+        rc = f(_ptr(Y), _sz(L), _sz(norm))
     assert rc == 0
-    return Y
+    assert buf[0] == 77.0 and buf[-1] == 77.0, f"{name} L={L}: the reference wrote outside its L values"
+    return Y.copy()
+
+
+def ref_convert_freqs(frqs, in_scale, out_scale):
+    """reference c/convert_freqs.c, on a copy."""
+    y = np.array(frqs, copy=True)
+    s, _ = _sfx(y.dtype)
+    f = getattr(ref(), f"convert_freqs_{s}")
+    f.restype = _int
+    rc = f(_ptr(y), _sz(y.size), in_scale.encode(), out_scale.encode())
+    return rc, y
 
 
 def normalised_err(Y, Yref):

@@ -539,6 +539,45 @@ def test_fused_power_compression_matches_two_step_oracle(O, D, dt):
 
 
 @pytest.mark.parametrize("tag", ["s", "d"])
+def test_more_window_generators_against_reference_fixtures(D, tag):
+    """blackman (both coefficient sets), bartlett, triangular, rectangular, flattop, gauss, tukey, planck
+    on the device vs the reference's own generators (fixtures; keys name[@par].L.nK), lengths 1, 2, 3, 7, 8,
+    400, 401, all four norms.  Same bounds as for the first four windows; the exponentials of gauss and
+    planck are a few ulp from libm's: 1e-6 float32."""
+    import torch
+    g = load_golden(f"ref_windows2_{tag}.npz")
+    dt = np.float32 if tag == "s" else np.float64
+    seen = 0
+    for key in g.files:
+        head, L, norm = key.split(".n")[0].rsplit(".", 1)[0], int(key.split(".n")[0].rsplit(".", 1)[1]), int(key.rsplit(".n", 1)[1])
+        name, _, par = head.partition("@")
+        kw = {}
+        if name == "blackman":
+            kw["exact"] = par == "1"
+        elif par:
+            kw["par"] = float(par)
+        ref = g[key]
+        y = D.window(name, L, norm, dt, **kw)
+        assert y.dtype == ref.dtype and y.shape == ref.shape
+        tol = (1e-6 if name in ("gauss", "planck") else 3e-7) if tag == "s" else 1e-14
+        bound = tol * (10 if norm in (1, 2) else 1) * np.max(np.abs(ref))
+        assert np.max(np.abs(y.astype(np.float64) - ref)) <= bound, (key, np.max(np.abs(y - ref)))
+        yd = D.window_dev(name, L, norm, torch.float32 if tag == "s" else torch.float64, **kw).cpu().numpy()
+        assert np.array_equal(y, yd)
+        seen += 1
+    assert seen >= 15 * (4 + 3 * 4) - 20
+    for name, bad in [("gauss", 0.0), ("gauss", -1.0), ("tukey", 1.5), ("tukey", -0.1), ("planck", 0.6), ("planck", -0.1)]:
+        with pytest.raises(D.DspError):
+            D.window(name, 16, 0, dt, par=bad)
+    with pytest.raises(D.DspError):
+        D.window("flattop", 16, 4, dt)
+    # where the reference writes past its L values or leaves the centre unwritten
+    assert np.array_equal(D.window("planck", 9, 0, dt, par=0.0), np.ones(9, dt))
+    y = D.window("planck", 9, 0, dt, par=0.5)
+    assert y[0] == 0 and np.array_equal(y, y[::-1]) and 0.5 < y[4] <= 1
+
+
+@pytest.mark.parametrize("tag", ["s", "d"])
 def test_window_generators_against_reference_fixtures(D, tag):
     """hann/hamming/povey/blackmanharris computed on the device vs what the reference's own generators
     returned (fixtures), all four norms.  Bound: absolute, relative to the window's largest element:

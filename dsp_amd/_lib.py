@@ -33,6 +33,7 @@ SIGNATURES = {
     "apply_win_inplace_s": (_int, _AWI), "apply_win_inplace_d": (_int, _AWI),
     "apply_win_inplace_c": (_int, _AWI), "apply_win_inplace_z": (_int, _AWI),
     "fft_fftw_r2hc_s": (_int, _R2HC), "fft_fftw_r2hc_d": (_int, _R2HC),
+    "fft_fftw_s": (_int, _R2HC), "fft_fftw_d": (_int, _R2HC), "fft_fftw_c": (_int, _R2HC), "fft_fftw_z": (_int, _R2HC),
     "dsp_stft_num_frames": (_sz, [_sz, _sz, _sz, _int]),
     "dsp_set_device": (_int, [_int]),
     "dsp_stft_flt_set_mode": (_int, [_int]),

@@ -179,6 +179,22 @@ def fft_r2hc(x, dim, nfft, iscolmajor=False, sc=False):
     return Y
 
 
+def fft(x, dim, nfft, iscolmajor=False, sc=False):
+    """fft_fftw_s / _d / _c / _z: FFT along dim; nfft//2+1 complex outputs for real x, nfft for complex x."""
+    order = "F" if iscolmajor else "C"
+    x = np.asarray(x)
+    s = {"float32": "s", "float64": "d", "complex64": "c", "complex128": "z"}[x.dtype.name]
+    xm = np.asarray(x, order=order)
+    R, Cc, S, H = _dims4(x.shape)
+    oshape = list(_dims4(x.shape))
+    oshape[dim] = nfft // 2 + 1 if s in "sd" else nfft
+    oshape = tuple(oshape[: max(x.ndim, dim + 1)])
+    Y = np.empty(oshape, dtype=np.complex64 if s in "sc" else np.complex128, order=order)
+    rc = getattr(lib(), f"fft_fftw_{s}")(_p(Y), _p(xm), R, Cc, S, H, int(bool(iscolmajor)), dim, nfft, int(bool(sc)))
+    _check(rc, f"fft_fftw_{s}")
+    return Y
+
+
 def fft_power(xc):
     """fft_power_c / _z: |x|^2 element-wise over a complex array."""
     xc = np.ascontiguousarray(xc)

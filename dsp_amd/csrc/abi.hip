@@ -605,7 +605,11 @@ int r2hc_host(const char *fn, T *Y, const T *X, size_t R, size_t C, size_t S, si
     if (dim > 3u) { fprintf(stderr, "error in %s: dim must be in [0 3]\n", fn); return 1; }
     const size_t sz[4] = {R, C, S, H};
     const size_t N = R * C * S * H, Lx = sz[dim], Ly = nfft / 2u + 1u;
-    if (nfft < Lx) { fprintf(stderr, "error in %s: nfft must be >= L (vec length)\n", fn); return 1; }
+    if (nfft < Lx) {                              // c/fft.fftw.r2hc.c:32 and c/fft.fftw.c:36 word it differently
+        const bool r2hc = strncmp(fn, "fft_fftw_r2hc", 13) == 0;
+        fprintf(stderr, r2hc ? "error in %s: nfft must be >= L (vec length)\n" : "error in %s: nfft must be >= Lx (vec length of vecs in X)\n", fn);
+        return 1;
+    }
     if (nfft == 0u || N == 0u) { return 0; }
     if (nfft > (size_t)INT_MAX / 4) { fprintf(stderr, "error in %s: nfft exceeds the supported index range\n", fn); return 1; }
     size_t K = 1;
@@ -627,6 +631,39 @@ int r2hc_host(const char *fn, T *Y, const T *X, size_t R, size_t C, size_t S, si
     HIPCHK(fn, hipMemcpy(dx, X, N * sizeof(T), hipMemcpyHostToDevice));
     const T scale = sc ? (T)(1.0 / sqrt((double)(2u * nfft))) : T(1);
     HIPCHK(fn, launch_r2hc<T>((T *)dy, (const T *)dx, tw, V, K, Lx, nfft, pow2, scale, nullptr));
+    HIPCHK(fn, hipMemcpy(Y, dy, yb, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// reference c/fft.fftw.c:194-272 (complex input, nfft complex outputs along dim; sc: 1/sqrt(2 nfft))
+template <typename T>
+int c2c_host(const char *fn, T *Y, const T *X, size_t R, size_t C, size_t S, size_t H, int iscolmajor, size_t dim, size_t nfft, int sc)
+{
+    if (dim > 3u) { fprintf(stderr, "error in %s: dim must be in [0 3]\n", fn); return 1; }
+    const size_t sz[4] = {R, C, S, H};
+    const size_t N = R * C * S * H, Lx = sz[dim];
+    if (nfft < Lx) { fprintf(stderr, "error in %s: nfft must be >= Lx (vec length of vecs in X)\n", fn); return 1; }
+    if (nfft == 0u || N == 0u) { return 0; }
+    if (nfft > (size_t)INT_MAX / 4) { fprintf(stderr, "error in %s: nfft exceeds the supported index range\n", fn); return 1; }
+    size_t K = 1;
+    if (iscolmajor) { for (size_t k = 0; k < dim; ++k) { K *= sz[k]; } }
+    else { for (size_t k = 3; k > dim; --k) { K *= sz[k]; } }
+    const size_t V = N / Lx;
+    const int pow2 = (nfft >= 2 && is_pow2(nfft)) ? 1 : 0;
+    if (2 * (pow2 ? nfft : Lx) * sizeof(T) > LDS_LIMIT) { fprintf(stderr, "error in %s: nfft too large (limit %zu)\n", fn, LDS_LIMIT / (2 * sizeof(T))); return 1; }
+    int dev;
+    if (use_device(fn, dev)) { return 1; }
+    const T *tw = nullptr;
+    if (get_twiddles<T>(fn, dev, nfft, pow2 ? 0 : 1, tw)) { return 1; }
+    DevState &st = g_dev[dev];
+    std::lock_guard<std::mutex> lk(st.ws_mu);
+    void *dx, *dy;
+    const size_t yb = 2 * V * nfft * sizeof(T);
+    if (ws_reserve(fn, st, 0, 2 * N * sizeof(T), dx)) { return 1; }
+    if (ws_reserve(fn, st, 1, yb, dy)) { return 1; }
+    HIPCHK(fn, hipMemcpy(dx, X, 2 * N * sizeof(T), hipMemcpyHostToDevice));
+    const T scale = sc ? (T)(1.0 / sqrt((double)(2u * nfft))) : T(1);
+    HIPCHK(fn, launch_c2c<T>((T *)dy, (const T *)dx, tw, V, K, Lx, nfft, pow2, scale, nullptr));
     HIPCHK(fn, hipMemcpy(Y, dy, yb, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -745,6 +782,15 @@ int fft_fftw_r2hc_s(float *Y, const float *X, const size_t R, const size_t C, co
 { return r2hc_host<float>("fft_fftw_r2hc_s", Y, X, R, C, S, H, iscolmajor, dim, nfft, sc); }
 int fft_fftw_r2hc_d(double *Y, const double *X, const size_t R, const size_t C, const size_t S, const size_t H, const int iscolmajor, const size_t dim, const size_t nfft, const int sc)
 { return r2hc_host<double>("fft_fftw_r2hc_d", Y, X, R, C, S, H, iscolmajor, dim, nfft, sc); }
+
+int fft_fftw_s(float *Y, const float *X, const size_t R, const size_t C, const size_t S, const size_t H, const int iscolmajor, const size_t dim, const size_t nfft, const int sc)
+{ return r2hc_host<float>("fft_fftw_s", Y, X, R, C, S, H, iscolmajor, dim, nfft, sc); }
+int fft_fftw_d(double *Y, const double *X, const size_t R, const size_t C, const size_t S, const size_t H, const int iscolmajor, const size_t dim, const size_t nfft, const int sc)
+{ return r2hc_host<double>("fft_fftw_d", Y, X, R, C, S, H, iscolmajor, dim, nfft, sc); }
+int fft_fftw_c(float *Y, const float *X, const size_t R, const size_t C, const size_t S, const size_t H, const int iscolmajor, const size_t dim, const size_t nfft, const int sc)
+{ return c2c_host<float>("fft_fftw_c", Y, X, R, C, S, H, iscolmajor, dim, nfft, sc); }
+int fft_fftw_z(double *Y, const double *X, const size_t R, const size_t C, const size_t S, const size_t H, const int iscolmajor, const size_t dim, const size_t nfft, const int sc)
+{ return c2c_host<double>("fft_fftw_z", Y, X, R, C, S, H, iscolmajor, dim, nfft, sc); }
 
 // ---------------------------------------- additions ----------------------------------------------
 size_t dsp_stft_num_frames(const size_t N, const size_t L, const size_t stp, const int snip_edges)

@@ -456,6 +456,83 @@ hipError_t launch_r2hc(T *Y, const T *X, const T *tw, size_t V, size_t K, size_t
     return hipGetLastError();
 }
 
+// reference c/fft.fftw.c:194-272 -- complex FFT of V vectors of Lx interleaved complex values (element
+// stride K complex values, vector v = (o, i): X + 2 (o K Lx + i)), zero-padded to nfft, nfft complex
+// outputs with the same stride.  pow2 != 0: radix-2 in LDS (tw: nfft/2 entries); else direct sum in
+// double (tw: nfft entries).
+template <typename T>
+__global__ __launch_bounds__(256) void c2c_kernel(T *__restrict__ Y, const T *__restrict__ X, const T *__restrict__ tw,
+                                                   const size_t V, const size_t K, const size_t Lx, const int nfft,
+                                                   const int pow2, const T scale)
+{
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T *buf = reinterpret_cast<T *>(smem_raw);
+    const int tid = threadIdx.x;
+    for (size_t v = blockIdx.x; v < V; v += gridDim.x) {
+        const size_t o = v / K, i = v - o * K;
+        const T *x = X + 2 * (o * K * Lx + i);
+        T *y = Y + 2 * (o * K * (size_t)nfft + i);
+        if (pow2) {
+            const int lg = 31 - __clz(nfft);
+            for (int l = tid; l < nfft; l += 256) {
+                const int r = (int)(__brev((unsigned)l) >> (32 - lg));
+                const bool in = (size_t)l < Lx;
+                buf[2 * r] = in ? x[2 * (size_t)l * K] : T(0);
+                buf[2 * r + 1] = in ? x[2 * (size_t)l * K + 1] : T(0);
+            }
+            __syncthreads();
+            for (int h = 1; h < nfft; h <<= 1) {
+                const int tstep = (nfft >> 1) / h;
+                for (int t = tid; t < (nfft >> 1); t += 256) {
+                    const int j = t & (h - 1);
+                    const int a = ((t - j) << 1) + j;
+                    const T wr = tw[2 * (j * tstep)], wi = tw[2 * (j * tstep) + 1];
+                    const T ar = buf[2 * a], ai = buf[2 * a + 1];
+                    const T br = buf[2 * (a + h)], bi = buf[2 * (a + h) + 1];
+                    const T tr = br * wr - bi * wi, ti = br * wi + bi * wr;
+                    buf[2 * a] = ar + tr; buf[2 * a + 1] = ai + ti;
+                    buf[2 * (a + h)] = ar - tr; buf[2 * (a + h) + 1] = ai - ti;
+                }
+                __syncthreads();
+            }
+            for (int k = tid; k < nfft; k += 256) {
+                y[2 * (size_t)k * K] = buf[2 * k] * scale;
+                y[2 * (size_t)k * K + 1] = buf[2 * k + 1] * scale;
+            }
+        } else {
+            for (int l = tid; (size_t)l < 2 * Lx; l += 256) { buf[l] = x[2 * (size_t)(l >> 1) * K + (l & 1)]; }
+            __syncthreads();
+            for (int k = tid; k < nfft; k += 256) {
+                int a = 0;
+                double re = 0.0, im = 0.0;
+                for (int l = 0; (size_t)l < Lx; ++l) {
+                    const double sr = (double)buf[2 * l], si = (double)buf[2 * l + 1];
+                    const double wr = (double)tw[2 * a], wi = (double)tw[2 * a + 1];
+                    re += sr * wr - si * wi;
+                    im += sr * wi + si * wr;
+                    a += k; if (a >= nfft) { a -= nfft; }
+                }
+                y[2 * (size_t)k * K] = (T)re * scale; y[2 * (size_t)k * K + 1] = (T)im * scale;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T>
+hipError_t launch_c2c(T *Y, const T *X, const T *tw, size_t V, size_t K, size_t Lx, size_t nfft, int pow2, T scale, hipStream_t s)
+{
+    if (V == 0) { return hipSuccess; }
+    const size_t lds = 2 * (pow2 ? nfft : Lx) * sizeof(T) + 64;
+    static LdsGrant grant;
+    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&c2c_kernel<T>), lds, grant); e != hipSuccess) { return e; }
+    const size_t grid = V < 8192 ? V : 8192;
+    hipLaunchKernelGGL(c2c_kernel<T>, dim3((unsigned)grid), dim3(256), lds, s, Y, X, tw, V, K, Lx, (int)nfft, pow2, scale);
+    return hipGetLastError();
+}
+template hipError_t launch_c2c<float>(float *, const float *, const float *, size_t, size_t, size_t, size_t, int, float, hipStream_t);
+template hipError_t launch_c2c<double>(double *, const double *, const double *, size_t, size_t, size_t, size_t, int, double, hipStream_t);
+
 template hipError_t launch_pow_compress<float>(float *, const float *, size_t, const Epilogue &, hipStream_t);
 template hipError_t launch_pow_compress<double>(double *, const double *, size_t, const Epilogue &, hipStream_t);
 template hipError_t launch_fft_power<float>(float *, const float *, size_t, hipStream_t);

@@ -135,5 +135,6 @@ template <typename T> hipError_t launch_pow_compress(T *Y, const T *X, size_t N,
 template <typename T> hipError_t launch_frames(T *Y, const T *X, const T *win, const FrameDesc &d, int E, hipStream_t s);
 template <typename T> hipError_t launch_apply_win(T *Y, const T *X1, const T *X2, size_t N, size_t stride_dim, size_t len_dim, int cplx, hipStream_t s);
 template <typename T> hipError_t launch_r2hc(T *Y, const T *X, const T *tw, size_t V, size_t K, size_t Lx, size_t nfft, int pow2, T scale, hipStream_t s);
+template <typename T> hipError_t launch_c2c(T *Y, const T *X, const T *tw, size_t V, size_t K, size_t Lx, size_t nfft, int pow2, T scale, hipStream_t s);
 
 }  // namespace dsp

@@ -80,6 +80,14 @@ int apply_win_inplace_z (double *X1, const double *X2, const size_t R, const siz
  * bounds, c/fft.fftw.r2hc.c:56-59,101-105; the mathematically intended result is returned.) */
 int fft_fftw_r2hc_s (float *Y, const float *X, const size_t R, const size_t C, const size_t S, const size_t H, const int iscolmajor, const size_t dim, const size_t nfft, const int sc);
 int fft_fftw_r2hc_d (double *Y, const double *X, const size_t R, const size_t C, const size_t S, const size_t H, const int iscolmajor, const size_t dim, const size_t nfft, const int sc);
+/* reference c/fft.fftw.c:23-26.  FFT of every vector along dim of a tensor of up to 4 dimensions,
+ * zero-padded to nfft.  _s/_d: real input, nfft/2+1 interleaved complex values along dim (the values
+ * of fft_fftw_r2hc); _c/_z: interleaved complex input, nfft complex values along dim.  sc scales by
+ * 1/sqrt(2 nfft). */
+int fft_fftw_s (float *Y, const float *X, const size_t R, const size_t C, const size_t S, const size_t H, const int iscolmajor, const size_t dim, const size_t nfft, const int sc);
+int fft_fftw_d (double *Y, const double *X, const size_t R, const size_t C, const size_t S, const size_t H, const int iscolmajor, const size_t dim, const size_t nfft, const int sc);
+int fft_fftw_c (float *Y, const float *X, const size_t R, const size_t C, const size_t S, const size_t H, const int iscolmajor, const size_t dim, const size_t nfft, const int sc);
+int fft_fftw_z (double *Y, const double *X, const size_t R, const size_t C, const size_t S, const size_t H, const int iscolmajor, const size_t dim, const size_t nfft, const int sc);
 
 /* reference c/hann.c:15-16, c/hamming.c:15-16, c/povey.c:15-16, c/blackmanharris.c:16-17.  The
  * window X2 of stft: symmetric, period L-1, L values; norm 0 none, 1 unit sum, 2 unit energy,

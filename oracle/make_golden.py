@@ -136,6 +136,17 @@ def main():
             d[f"in.{a}"] = xa
         np.savez_compressed(os.path.join(OUT, f"ref_convert_freqs_{tag}.npz"), **d)
 
+        # complex FFT rows through the reference's own radix-2 code (fft_rad2_c/_z)
+        d = {}
+        cdt = np.complex64 if tag == "s" else np.complex128
+        for n in (2, 8, 64, 512):
+            xc = (rng.standard_normal((5, n)) + 1j * rng.standard_normal((5, n))).astype(cdt)
+            rc, yc = O.ref_fft_rad2_c(xc)
+            assert rc == 0
+            d[f"x.{n}"] = xc
+            d[f"y.{n}"] = yc
+        np.savez_compressed(os.path.join(OUT, f"ref_fft_c_{tag}.npz"), **d)
+
         # complex framing / windowing (frame_univar_c/z, frame_univar_flt_c/z, apply_win_c/z in place form)
         d = {}
         rng = np.random.default_rng(5)

@@ -201,6 +201,45 @@ def fft_r2hc(x, dim, nfft, iscolmajor=False, sc=False, exact=True):
     return rc, Y
 
 
+def fft(x, dim, nfft, iscolmajor=False, sc=False):
+    """Oracle for fft_fftw_s/_d/_c/_z (reference c/fft.fftw.c:29-111,194-272): the published forward DFT
+    X[k] = sum_n x[n] exp(-2 pi i k n / nfft) of every vector along dim, zero-padded to nfft, evaluated
+    in double precision (the arithmetic itself is FFTW's, which is not in the reference tree); real
+    input keeps bins 0..nfft/2, complex input all nfft; sc multiplies by 1/sqrt(2 nfft) (c/fft.fftw.c:104-108).
+    The memory order of the tensor is numpy's business here: the result has the order asked for.
+    Returns (rc, complex Y)."""
+    x = np.asarray(x)
+    if dim > 3:
+        return 1, None
+    shape4 = _dims4(x.shape)
+    if nfft < shape4[dim]:
+        return 1, None
+    real = x.dtype in (np.float32, np.float64)
+    cdt = np.complex64 if x.dtype in (np.float32, np.complex64) else np.complex128
+    x4 = x.reshape(shape4).astype(np.complex128)
+    Y = np.fft.fft(x4, n=nfft, axis=dim) if nfft > 0 else np.zeros(shape4, np.complex128)
+    if real:
+        Y = np.take(Y, np.arange(nfft // 2 + 1), axis=dim)
+    if sc and nfft > 0:
+        Y = Y * (1.0 / np.sqrt(2.0 * nfft))
+    oshape = Y.shape[: max(x.ndim, dim + 1)]
+    return 0, np.asarray(Y.reshape(oshape).astype(cdt), order="F" if iscolmajor else "C")
+
+
+def ref_fft_rad2_c(xc):
+    """The reference's own radix-2 complex FFT (c/fft.rad2.c, fft_rad2_c/_z) of each row of xc[V, nfft]
+    (nfft a power of two, rows already of full length: the entry point's own zero-padding loop does not
+    advance its pointer, c/fft.rad2.c:576)."""
+    xc = np.ascontiguousarray(xc)
+    V, n = xc.shape
+    s = "c" if xc.dtype == np.complex64 else "z"
+    Y = np.zeros((V, n), dtype=xc.dtype)
+    f = getattr(ref(), f"fft_rad2_{s}")
+    f.restype = _int
+    rc = f(_ptr(Y), _ptr(xc), _sz(V), _sz(n), _sz(1), _sz(1), _int(0), _sz(1), _sz(n), _int(0))
+    return rc, Y
+
+
 def ref_fft_rad2(frames, nfft):
     """The reference's own radix-2 FFT (c/fft.rad2.c) applied to each row of frames[W, L], zero-padded
     to nfft, returning the first nfft//2+1 bins (the layout of fft.fftw.r2hc).

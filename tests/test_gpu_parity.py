@@ -316,6 +316,42 @@ def test_fft_r2hc(O, D, dt):
                     assert np.all(ym[..., nfft // 2].imag == 0)
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64, np.complex64, np.complex128])
+def test_fft_fftw(O, D, dt):
+    """fft_fftw_s/_d/_c/_z along any dim of tensors of up to 4 dimensions, both memory orders, with and
+    without sc, power-of-two and other nfft, zero-padded; complex rows also against what the reference's
+    own radix-2 code returned (fixtures)."""
+    rng = np.random.default_rng(16)
+    rdt = np.float32 if dt in (np.float32, np.complex64) else np.float64
+    tol = 10 * TOL[np.dtype(rdt)]
+    cplx = dt in (np.complex64, np.complex128)
+    for shape, dim, nfft in [((13, 400), 1, 512), ((400, 13), 0, 512), ((3, 50, 4), 1, 64), ((2, 3, 4, 20), 3, 32),
+                             ((5, 30), 1, 45), ((5, 30), 1, 30), ((4, 7), 1, 8), ((9,), 0, 16), ((4, 1), 1, 1),
+                             ((3, 2, 5), 2, 5), ((6, 2000), 1, 4096)]:
+        x = rng.standard_normal(shape).astype(rdt)
+        if cplx:
+            x = (x + 1j * rng.standard_normal(shape)).astype(dt)
+        for col in (False, True):
+            for sc in (False, True):
+                rc, ref = O.fft(x, dim, nfft, col, sc)
+                assert rc == 0
+                y = D.fft(x, dim, nfft, col, sc)
+                assert y.shape == ref.shape and y.dtype == ref.dtype
+                assert y.shape[dim] == (nfft if cplx else nfft // 2 + 1)
+                assert np.max(np.abs(np.asarray(y) - np.asarray(ref))) <= tol * np.max(np.abs(ref))
+    if cplx:
+        g = load_golden(f"ref_fft_c_{'s' if dt == np.complex64 else 'd'}.npz")
+        for n in (2, 8, 64, 512):
+            y = D.fft(g[f"x.{n}"], 1, n)
+            assert np.max(np.abs(y - g[f"y.{n}"])) <= (3e-6 if dt == np.complex64 else 2e-14) * np.max(np.abs(g[f"y.{n}"]))
+    else:
+        # the real transform is the r2hc one
+        x = rng.standard_normal((7, 300)).astype(dt)
+        assert np.array_equal(D.fft(x, 1, 512, False, True), D.fft_r2hc(x, 1, 512, False, True))
+    with pytest.raises(D.DspError):
+        D.fft(np.zeros((3, 9), dt), 1, 8)
+
+
 @pytest.mark.parametrize("dt", [np.complex64, np.complex128])
 def test_fft_power(O, D, dt):
     rng = np.random.default_rng(7)

@@ -121,3 +121,22 @@ def test_complex_framing_and_apply_win(O, tag):
         rc, y1 = O.apply_win(a, g["aw.w1"], 1, bool(col))
         assert np.array_equal(np.ascontiguousarray(y0), g[f"aw.dim0.col{col}"])
         assert np.array_equal(np.ascontiguousarray(y1), g[f"aw.dim1.col{col}"])
+
+
+@pytest.mark.parametrize("tag", ["s", "d"])
+def test_fft_oracle_against_reference_radix2(O, tag):
+    """The DFT restatement behind fft_fftw_* vs what the reference's own fft_rad2_c/_z returned (fixtures);
+    the bound is that code's float twiddle recurrence, as for the chain fixtures.  Real input: the bins
+    0..nfft/2 of the complex transform, which is also what the r2hc oracle returns."""
+    g = load_golden(f"ref_fft_c_{tag}.npz")
+    for n in (2, 8, 64, 512):
+        x, yref = g[f"x.{n}"], g[f"y.{n}"]
+        rc, y = O.fft(x, 1, n)
+        assert rc == 0 and y.shape == yref.shape and y.dtype == yref.dtype
+        assert np.max(np.abs(y - yref)) <= PTOL[tag] * np.max(np.abs(yref))
+        xr = np.ascontiguousarray(x.real)
+        rc, yr = O.fft(xr, 1, n, sc=True)
+        rc2, yh = O.fft_r2hc(xr, 1, n, False, True)
+        assert rc == 0 and rc2 == 0
+        assert np.max(np.abs(yr - yh)) <= 4 * np.finfo(yr.real.dtype).eps * np.max(np.abs(yh))
+    assert O.fft(np.zeros((3, 9), np.float32), 1, 8)[0] == 1

@@ -44,6 +44,8 @@ SIGNATURES = {
     "dsp_fft_power_dev_c": (_int, [_vp, _vp, _sz, _vp]), "dsp_fft_power_dev_z": (_int, [_vp, _vp, _sz, _vp]),
     "window_univar_s": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _int]), "window_univar_d": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _int]),
     "window_univar_flt_s": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _f, _f]), "window_univar_flt_d": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _d, _d]),
+    "window_univar_c": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _int]), "window_univar_z": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _int]),
+    "window_univar_flt_c": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _f, _f]), "window_univar_flt_z": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _d, _d]),
     "hann_s": (_int, [_vp, _sz, _sz]), "hann_d": (_int, [_vp, _sz, _sz]),
     "hamming_s": (_int, [_vp, _sz, _sz]), "hamming_d": (_int, [_vp, _sz, _sz]),
     "povey_s": (_int, [_vp, _sz, _sz]), "povey_d": (_int, [_vp, _sz, _sz]),

@@ -205,11 +205,16 @@ def fft_power(xc):
     return Y
 
 
+_ANY_SFX = {"float32": "s", "float64": "d", "complex64": "c", "complex128": "z"}
+_REAL_OF = {"s": np.float32, "d": np.float64, "c": np.float32, "z": np.float64}
+
+
 def window_univar(x, win, stp, snip_edges=False):
-    """window_univar_s / _d: frames of x, each multiplied by win; returns Y[W, L]."""
+    """window_univar_s / _d / _c / _z: frames of x (real or complex), each multiplied by the real window
+    win; returns Y[W, L]."""
     x = np.ascontiguousarray(x)
-    s = _real_sfx(x.dtype)
-    win = np.ascontiguousarray(win, dtype=x.dtype)
+    s = _ANY_SFX[x.dtype.name]
+    win = np.ascontiguousarray(win, dtype=_REAL_OF[s])
     W = num_frames(x.size, win.size, stp, snip_edges)
     Y = np.empty((W, win.size), dtype=x.dtype)
     rc = getattr(lib(), f"window_univar_{s}")(_p(Y), _p(x), _p(win), x.size, win.size, stp, int(bool(snip_edges)))
@@ -218,10 +223,11 @@ def window_univar(x, win, stp, snip_edges=False):
 
 
 def window_univar_flt(x, win, W, c0, stp):
-    """window_univar_flt_s / _d: W zero-edged frames centred at round(c0 + w*stp), each multiplied by win."""
+    """window_univar_flt_s / _d / _c / _z: W zero-edged frames centred at round(c0 + w*stp), each
+    multiplied by the real window win."""
     x = np.ascontiguousarray(x)
-    s = _real_sfx(x.dtype)
-    win = np.ascontiguousarray(win, dtype=x.dtype)
+    s = _ANY_SFX[x.dtype.name]
+    win = np.ascontiguousarray(win, dtype=_REAL_OF[s])
     Y = np.empty((W, win.size), dtype=x.dtype)
     rc = getattr(lib(), f"window_univar_flt_{s}")(_p(Y), _p(x), _p(win), x.size, win.size, W, float(c0), float(stp))
     _check(rc, f"window_univar_flt_{s}")

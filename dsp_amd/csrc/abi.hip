@@ -691,6 +691,14 @@ int window_univar_flt_s(float *Y, const float *X1, const float *X2, const size_t
 { return frame_univar_flt_host<float>("window_univar_flt_s", Y, X1, N, L, W, c0, stp, 1, X2); }
 int window_univar_flt_d(double *Y, const double *X1, const double *X2, const size_t N, const size_t L, const size_t W, const double c0, const double stp)
 { return frame_univar_flt_host<double>("window_univar_flt_d", Y, X1, N, L, W, c0, stp, 1, X2); }
+int window_univar_c(float *Y, const float *X1, const float *X2, const size_t N, const size_t L, const size_t stp, const int snip_edges)
+{ return frame_univar_host<float>("window_univar_c", Y, X1, N, L, stp, snip_edges, 2, X2); }
+int window_univar_z(double *Y, const double *X1, const double *X2, const size_t N, const size_t L, const size_t stp, const int snip_edges)
+{ return frame_univar_host<double>("window_univar_z", Y, X1, N, L, stp, snip_edges, 2, X2); }
+int window_univar_flt_c(float *Y, const float *X1, const float *X2, const size_t N, const size_t L, const size_t W, const float c0, const float stp)
+{ return frame_univar_flt_host<float>("window_univar_flt_c", Y, X1, N, L, W, c0, stp, 2, X2); }
+int window_univar_flt_z(double *Y, const double *X1, const double *X2, const size_t N, const size_t L, const size_t W, const double c0, const double stp)
+{ return frame_univar_flt_host<double>("window_univar_flt_z", Y, X1, N, L, W, c0, stp, 2, X2); }
 int hann_s(float *Y, const size_t L, const size_t norm) { return window_host<float>("hann_s", Y, L, norm, 0); }
 int hann_d(double *Y, const size_t L, const size_t norm) { return window_host<double>("hann_d", Y, L, norm, 0); }
 int hamming_s(float *Y, const size_t L, const size_t norm) { return window_host<float>("hamming_s", Y, L, norm, 1); }

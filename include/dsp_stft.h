@@ -60,6 +60,15 @@ int window_univar_s (float *Y, const float *X1, const float *X2, const size_t N,
 int window_univar_d (double *Y, const double *X1, const double *X2, const size_t N, const size_t L, const size_t stp, const int snip_edges);
 int window_univar_flt_s (float *Y, const float *X1, const float *X2, const size_t N, const size_t L, const size_t W, const float c0, const float stp);
 int window_univar_flt_d (double *Y, const double *X1, const double *X2, const size_t N, const size_t L, const size_t W, const double c0, const double stp);
+/* reference c/window_univar.c:37-38, c/window_univar_flt.c:25-26.  The same for a complex signal
+ * (N interleaved values) and a REAL window of L values: both parts of a sample are multiplied by the
+ * window value.  (After a frame that lies inside the signal the reference's window_univar_c/_z steps
+ * back L-stp floats instead of complex values, c/window_univar.c:156-159,184-186, and reads past the
+ * signal unless stp == L; the frames of frame_univar_c/_z times the window are returned here.) */
+int window_univar_c (float *Y, const float *X1, const float *X2, const size_t N, const size_t L, const size_t stp, const int snip_edges);
+int window_univar_z (double *Y, const double *X1, const double *X2, const size_t N, const size_t L, const size_t stp, const int snip_edges);
+int window_univar_flt_c (float *Y, const float *X1, const float *X2, const size_t N, const size_t L, const size_t W, const float c0, const float stp);
+int window_univar_flt_z (double *Y, const double *X1, const double *X2, const size_t N, const size_t L, const size_t W, const double c0, const double stp);
 
 /* reference c/apply_win.c:15-23.  Y = X1 .* X2, X2 (length L) broadcast along dim of the
  * R x C x S x H tensor X1, row- or column-major; the _c/_z forms multiply complex by complex.

@@ -147,6 +147,29 @@ def main():
             d[f"y.{n}"] = yc
         np.savez_compressed(os.path.join(OUT, f"ref_fft_c_{tag}.npz"), **d)
 
+        # window_univar_c/z and window_univar_flt_c/z on a complex signal with a real window.  After a
+        # frame that lies inside the signal window_univar_c/z steps back L-stp floats, not complex values
+        # (c/window_univar.c:156-159,184-186), and reads past the signal from then on: only hop = L and
+        # signals shorter than the window (every frame reflected) give defined output
+        d = {}
+        rngc = np.random.default_rng(31)
+        xc = (rngc.standard_normal(700) + 1j * rngc.standard_normal(700)).astype(cdt)
+        h = O.ref_window("hamming", 48, dt)
+        d["x"] = xc; d["win"] = h
+        for stp in (48,):
+            rc, y = O.ref_window_univar(xc, h, stp, False)
+            assert rc == 0
+            d[f"wu.stp{stp}"] = y
+        rc, y = O.ref_window_univar(xc[:30], h, 20, False)      # N < L: repeated reflection
+        assert rc == 0
+        d["wu.short"] = y
+        for i, (W, c0, stp) in enumerate([(30, -10.0, 17.3), (40, 24.0, 20.0), (25, 600.0, 9.5)]):
+            rc, y = O.ref_window_univar_flt(xc, h, W, c0, stp)
+            assert rc == 0
+            d[f"wuf.{i}"] = y
+            d[f"wuf.{i}.par"] = np.array([W, c0, stp])
+        np.savez_compressed(os.path.join(OUT, f"ref_wu_c_{tag}.npz"), **d)
+
         # complex framing / windowing (frame_univar_c/z, frame_univar_flt_c/z, apply_win_c/z in place form)
         d = {}
         rng = np.random.default_rng(5)

@@ -280,11 +280,17 @@ def ref_fft_power(xc):
     return rc, Y
 
 
+def _wu_types(x):
+    """suffix, real dtype and C scalar type of a real or complex signal"""
+    return {"float32": ("s", np.float32, C.c_float), "float64": ("d", np.float64, C.c_double),
+            "complex64": ("c", np.float32, C.c_float), "complex128": ("z", np.float64, C.c_double)}[x.dtype.name]
+
+
 def ref_window_univar(x, win, stp, snip_edges=False):
-    """reference c/window_univar.c: frame + window, no FFT."""
+    """reference c/window_univar.c: frame + window, no FFT (x real or complex, win real)."""
     x = np.ascontiguousarray(x)
-    s, _ = _sfx(x.dtype)
-    win = np.ascontiguousarray(win, dtype=x.dtype)
+    s, rdt, _ = _wu_types(x)
+    win = np.ascontiguousarray(win, dtype=rdt)
     W = num_frames(x.size, win.size, stp, snip_edges)
     Y = np.zeros((W, win.size), dtype=x.dtype)
     f = getattr(ref(), f"window_univar_{s}")
@@ -294,10 +300,10 @@ def ref_window_univar(x, win, stp, snip_edges=False):
 
 
 def ref_window_univar_flt(x, win, W, c0, stp):
-    """reference c/window_univar_flt.c: frame + window with the _flt conventions."""
+    """reference c/window_univar_flt.c: frame + window with the _flt conventions (x real or complex)."""
     x = np.ascontiguousarray(x)
-    s, ct = _sfx(x.dtype)
-    win = np.ascontiguousarray(win, dtype=x.dtype)
+    s, rdt, ct = _wu_types(x)
+    win = np.ascontiguousarray(win, dtype=rdt)
     Y = np.zeros((W, win.size), dtype=x.dtype)
     f = getattr(ref(), f"window_univar_flt_{s}")
     f.restype = _int

@@ -673,3 +673,19 @@ def test_window_univar_against_reference_fixtures(O, D, tag):
     assert np.array_equal(D.window_univar(x, win, 77), fr * win[None, :])
     with pytest.raises(D.DspError):
         D.window_univar(x[:100], win, 10, True)
+    # complex signal, real window (window_univar_c/_z, window_univar_flt_c/_z)
+    g = load_golden(f"ref_wu_c_{tag}.npz")
+    xc, h = g["x"], g["win"]
+    assert np.array_equal(D.window_univar(xc, h, 48), g["wu.stp48"])
+    assert np.array_equal(D.window_univar(xc[:30], h, 20), g["wu.short"])
+    # other hops: the reference's complex form steps back floats instead of complex values after a frame
+    # inside the signal (c/window_univar.c:184-186) and reads past it; the complex framing itself is pinned
+    for stp in (20, 61):
+        rc, fr = O.frame_univar(xc, h.size, stp, 0)
+        assert np.array_equal(D.window_univar(xc, h, stp), fr * h[None, :])
+    for i in range(3):
+        W, c0, stp = g[f"wuf.{i}.par"]
+        assert np.array_equal(D.window_univar_flt(xc, h, int(W), c0, stp), g[f"wuf.{i}"])
+    # with snipped edges the reference's complex form mis-steps; frame w starts at w * stp here
+    rc, fr = O.frame_univar(xc, h.size, 20, 1)
+    assert np.array_equal(D.window_univar(xc, h, 20, True), fr * h[None, :])

@@ -223,6 +223,11 @@ int family_of(size_t nfft)
     if (!is_pow2(nfft)) { return 1; }
     if (nfft == 512 && !g_force_generic.load()) { return 3; }
     if (nfft == 4096 && sizeof(T) == 4 && !g_force_generic.load()) { return 4; }
+    if (!g_force_generic.load() && nfft <= (1u << 20)) {
+        FrameDesc probe{};
+        probe.nfft = (int)nfft; probe.L = 1;
+        if (wave_fft_supported<T>(probe)) { return 5; }
+    }
     return 2;
 }
 
@@ -249,6 +254,10 @@ int run_fused(const char *fn, int dev, T *Yd, const T *Xd, const T *wd, const Fr
             HIPCHK(fn, launch_stft_r4096(Yd, Xd, wd, tw, d, s));
             return 0;
         }
+    }
+    if (fam == 5 && wave_fft_supported<T>(d)) {
+        HIPCHK(fn, launch_stft_wave<T>(Yd, Xd, wd, tw, d, s));
+        return 0;
     }
     if (nfft * sizeof(T) > LDS_LIMIT) { fprintf(stderr, "error in %s: nfft too large (limit %zu)\n", fn, LDS_LIMIT / sizeof(T)); return 1; }
     HIPCHK(fn, launch_stft_pow2<T>(Yd, Xd, wd, tw, d, s));

@@ -114,6 +114,34 @@ def test_both_512_families_agree_with_oracle(O, D, dt):
             check_spec(O, Y, Yref)
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_both_power_of_two_families_agree_with_oracle(O, D, dt):
+    """Power-of-two nfft without a kernel of its own: the wavefront-per-frame kernels (family 5: nfft 16
+    to 4096 float32 / 1024 float64) and the workgroup-per-frame kernel (family 2) must each meet the bound:
+    every size, short and odd windows, odd hops, a signal shorter than the window, every flag."""
+    top = 2048 if dt == np.float32 else 1024
+    assert D.kernel_family(top, dt) == 5 and D.kernel_family(2 * top if dt == np.float64 else 8192, dt) == 2
+    cases = [(nfft, nfft, max(1, nfft // 4), (0, 0, 0)) for nfft in (16, 32, 64, 128, 256, 1024, 2048) if nfft <= top]
+    cases += [(16, 9, 3, (1, 0, 0)), (64, 33, 7, (0, 1, 0)), (256, 200, 80, (1, 1, 1)), (1024, 801, 321, (1, 0, 1)),
+              (1024, 1, 500, (0, 0, 0)), (128, 128, 1000, (0, 1, 1))]
+    for (nfft, L, stp, flags) in cases:
+        for N in (20 * L + 13, max(2, L // 2)):
+            x = signal(nfft + N, N, dt) + dt(0.1)
+            win = D.povey(L, dt)
+            for snip in (0, 1):
+                if snip and L > N:
+                    continue
+                rc, Yref = O.stft(x, win, stp, nfft, snip, *flags)
+                assert rc == 0
+                for generic in (False, True):
+                    D.force_generic(generic)
+                    try:
+                        Y = D.stft(x, win, stp, bool(snip), *[bool(f) for f in flags], nfft=nfft)
+                    finally:
+                        D.force_generic(False)
+                    check_spec(O, Y, Yref, flags[1], flags[2])
+
+
 def test_both_4096_families_agree_with_oracle(O, D):
     """nfft 4096 (float32) has a register-resident kernel beside the generic one; each must meet the
     bound on its own: full and short windows, odd hop (unaligned frame starts), a signal shorter

@@ -29,9 +29,10 @@ __host__ __device__ constexpr int wpad(int i) { return i + (i >> 4); }
 constexpr int wave_cap(int M, int elem) { return M / 64 < 4 ? 4 : (M / 64 > (elem == 4 ? 16 : 8) ? (elem == 4 ? 16 : 8) : M / 64); }
 constexpr int wave_radix(int rem, int cap) { return rem < cap ? rem : cap; }
 constexpr int wave_slots(int M) { return wpad(M) + 1; }
-// waves per CU worth having: the short transforms leave lanes idle and gain from 16 (measured, nfft 256:
-// 0.92 -> 0.59 ms); from M = 512 on more than 8 only add LDS traffic (nfft 1024: 1.07 -> 1.18 ms)
-constexpr int wave_target(int M) { return M <= 256 ? 16 : 8; }
+// waves per CU worth having: the kernels wait on LDS round trips more than they compute, so as many as the
+// registers allow: 16 for the short transforms, 12 above (measured, nfft 256: 0.92 ms at 8 waves, 0.59 at
+// 16; nfft 1024 at 129 registers: 1.07 ms at 8, 0.82 at 12, 1.18 at 14 in two workgroups of 7)
+constexpr int wave_target(int M) { return M <= 256 ? 16 : 12; }
 // LDS of a workgroup of wpw waves: the twiddles of the full circle (2 M), the window (M pairs) and two
 // buffers per wave
 constexpr long wave_lds_of(int M, int elem, int wpw) { return (3L * M + 2L * wave_slots(M) * wpw) * 2 * elem; }

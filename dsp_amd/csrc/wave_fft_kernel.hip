@@ -33,9 +33,23 @@ constexpr int wave_slots(int M) { return wpad(M) + 1; }
 // registers allow: 16 for the short transforms, 12 above (measured, nfft 256: 0.92 ms at 8 waves, 0.59 at
 // 16; nfft 1024 at 129 registers: 1.07 ms at 8, 0.82 at 12, 1.18 at 14 in two workgroups of 7)
 constexpr int wave_target(int M) { return M <= 256 ? 16 : 12; }
-// LDS of a workgroup of wpw waves: the twiddles of the full circle (2 M), the window (M pairs) and two
-// buffers per wave
-constexpr long wave_lds_of(int M, int elem, int wpw) { return (3L * M + 2L * wave_slots(M) * wpw) * 2 * elem; }
+// Pass twiddles: the pass that starts at sub-transform length ns (radix R) multiplies input t of butterfly
+// j by W_{ns R}^{k t}, k = j mod ns.  They are laid out per pass as [t - 1][k], so that the lanes of a wave
+// read consecutive entries at a compile-time offset.  Offset of the pass that starts at ns_target (the
+// first pass has none); with ns_target = M: the size of the whole table.
+constexpr int wave_tw_off(int M, int elem, int ns_target)
+{
+    int off = 0;
+    for (int ns = 1; ns < ns_target;) {
+        const int R = wave_radix(M / ns, wave_cap(M, elem));
+        if (ns > 1) { off += (R - 1) * ns; }
+        ns *= R;
+    }
+    return off;
+}
+// LDS of a workgroup of wpw waves: W_nfft^k, k < M, for the split; the pass twiddles; the window (M
+// pairs); two buffers per wave
+constexpr long wave_lds_of(int M, int elem, int wpw) { return (2L * M + wave_tw_off(M, elem, M) + 2L * wave_slots(M) * wpw) * 2 * elem; }
 // waves per workgroup (1..8): the smallest count that puts the most waves (up to wave_target) on a CU's
 // 160 KB; 0: the buffers do not fit at all
 constexpr int wave_wpw(int M, int elem)
@@ -70,14 +84,14 @@ __device__ __forceinline__ void dft8c(cx<T> (&v)[8])
 
 // One Stockham pass of radix R over M points: butterfly j reads src[j + t M/R], multiplies input t by
 // W_{NS R}^{k t} (k = j mod NS, NS = product of the radices of the passes before) and writes output t to
-// dst[(j - k) R + k + t NS].  tw: W_2M^m for all m < 2M.
+// dst[(j - k) R + k + t NS].  tw: the pass twiddles (wave_tw_off).
 template <typename T, int M, int R, int NS>
 __device__ __forceinline__ void wave_pass(const cx<T> *src, cx<T> *dst, const cx<T> *tw, const int lane)
 {
     using C = cx<T>;
     constexpr int NB = M / R;                              // butterflies
     constexpr int IT = NB >= 64 ? NB / 64 : 1;
-    constexpr int TMUL = 2 * M / (NS * R);
+    constexpr int OFF = wave_tw_off(M, (int)sizeof(T), NS);
 #pragma unroll 1
     for (int i = 0; i < IT; ++i) {                         // rolled: unrolled, the copies' registers add up
         const int j = lane + 64 * i;
@@ -88,7 +102,7 @@ __device__ __forceinline__ void wave_pass(const cx<T> *src, cx<T> *dst, const cx
         for (int t = 0; t < R; ++t) { v[t] = src[wpad(j + t * NB)]; }
         if (NS > 1) {
 #pragma unroll
-            for (int t = 1; t < R; ++t) { v[t] = cx_mul<T>(v[t], tw[k * (t * TMUL)]); }
+            for (int t = 1; t < R; ++t) { v[t] = cx_mul<T>(v[t], tw[OFF + (t - 1) * NS + k]); }
         }
         const int base = (j - k) * R + k;
         if constexpr (R == 16) {
@@ -102,6 +116,27 @@ __device__ __forceinline__ void wave_pass(const cx<T> *src, cx<T> *dst, const cx
 #pragma unroll
             for (int t = 0; t < R; ++t) { dst[wpad(base + t * NS)] = v[t]; }
         }
+    }
+}
+
+// the pass twiddles from sub-transform length NS on, from the table W_2M^m, m < M, in global memory
+template <typename T, int M, int NS>
+__device__ __forceinline__ void wave_fill_tw(cx<T> *ptw, const T *__restrict__ tw, const int tid, const int nthr)
+{
+    if constexpr (NS < M) {
+        constexpr int R = wave_radix(M / NS, wave_cap(M, (int)sizeof(T)));
+        if constexpr (NS > 1) {
+            constexpr int OFF = wave_tw_off(M, (int)sizeof(T), NS);
+            constexpr int TMUL = 2 * M / (NS * R);
+            for (int idx = tid; idx < (R - 1) * NS; idx += nthr) {
+                const int t = idx / NS + 1, k = idx - (t - 1) * NS;
+                const int e = k * t * TMUL;                  // < 2 M; the second half of the circle is the first negated
+                const int h = e < M ? e : e - M;
+                const T sg = e < M ? T(1) : T(-1);
+                ptw[OFF + idx] = cx_make<T>(sg * tw[2 * h], sg * tw[2 * h + 1]);
+            }
+        }
+        wave_fill_tw<T, M, NS * R>(ptw, tw, tid, nthr);
     }
 }
 
@@ -136,18 +171,19 @@ __global__ __launch_bounds__(64 * wave_wpw(NFFT / 2, (int)sizeof(T)), 2) void st
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int L = d.L;
 
-    // LDS: [twiddles W_nfft^m, m < nfft (the second half of the circle is the first negated)][window as M
-    // pairs, zero past L] then per wave two buffers of M (padded) complex points
+    // LDS: [W_nfft^m, m < M, for the split][pass twiddles][window as M pairs, zero past L] then per wave two
+    // buffers of M (padded) complex points
+    constexpr int TWN = wave_tw_off(M, (int)sizeof(T), M);
     C *twl = reinterpret_cast<C *>(smem_raw);
-    C *wl = twl + 2 * M;
+    C *ptw = twl + M;
+    C *wl = ptw + TWN;
     C *buf0 = wl + M + (size_t)wv * 2 * SLOTS;
     C *buf1 = buf0 + SLOTS;
     for (int m = tid; m < M; m += 64 * WPW) {
-        const T c = tw[2 * m], sn = tw[2 * m + 1];
-        twl[m] = cx_make<T>(c, sn);
-        twl[M + m] = cx_make<T>(-c, -sn);
+        twl[m] = cx_make<T>(tw[2 * m], tw[2 * m + 1]);
         wl[m] = cx_make<T>(2 * m < L ? win[2 * m] : T(0), 2 * m + 1 < L ? win[2 * m + 1] : T(0));
     }
+    wave_fill_tw<T, M, 1>(ptw, tw, tid, 64 * WPW);
     __syncthreads();
 
     const long long total = (long long)d.B * d.W;
@@ -238,7 +274,7 @@ __global__ __launch_bounds__(64 * wave_wpw(NFFT / 2, (int)sizeof(T)), 2) void st
         }
         wave_sync();
 
-        const C *res = wave_passes<T, M, 1>(buf0, buf1, twl, lane);
+        const C *res = wave_passes<T, M, 1>(buf0, buf1, ptw, lane);
 
         // real-FFT split fused with power: with A = Z_k + conj Z_{M-k}, B = Z_k - conj Z_{M-k},
         // X_k = (A - i W^k B)/2 and X_{M-k} = conj((A + i W^k B)/2)

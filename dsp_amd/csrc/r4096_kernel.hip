@@ -503,8 +503,8 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
                 if (m > 0) { B = cx_mul<float>(B, W64C[8 * m], W64C[8 * m + 1]); }
                 const C2 Tw = cx_mul<float>(B, ow4[c]);
                 p[c] = cx_norm<float>(A + Tw); q[c] = cx_norm<float>(A - Tw);
-                if (EPI) { p[c] = power_epilogue(p[c], a.epi); q[c] = power_epilogue(q[c], a.epi); }
             }
+            if (EPI) { power_epilogue_n(p, a.epi); power_epilogue_n(q, a.epi); }
             const int k0 = 4 * lane + 256 * m;
 #if R4096_ABLATE & 1
             asm volatile("" :: "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]));

@@ -354,8 +354,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
             pw[8 + k2] = cx_norm<T>(A - Tw);
         }
         if (EPI) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { pw[i] = power_epilogue(pw[i], a.epi); }
+            power_epilogue_n(pw, a.epi);
             p128 = power_epilogue(p128, a.epi);
         }
         wave_sync();                                       // every lane has read its tile row: reuse the region

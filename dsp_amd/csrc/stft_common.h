@@ -67,6 +67,32 @@ __device__ __forceinline__ float epi_log(float v)
     return (fabsf(l2) == __builtin_inff()) ? l2 : r;                  // log(0) = -inf, log(inf) = inf (inf - inf above)
 }
 __device__ __forceinline__ double epi_log(double v) { return log(v); }
+// Cube root and power of the same values.  float: from the hardware's log2 and exp2, ~10 instructions
+// instead of the library's 40 to 80, which made the fused cube-root epilogue cost two thirds of the
+// whole 512-point kernel (0.65 ms against 0.40).  cbrt: exp2(log2|v| / 3) and one Newton step (to about
+// 1 ulp).  pow: log2 v refined by one step (v 2^-l0 - 1) / ln 2, the product with p carried in two parts,
+// exp2 of the high part times 1 + ln 2 (low part): about 2 ulp.  Zero, infinities and NaN as the library.
+__device__ __forceinline__ float epi_cbrt(float v)
+{
+    const float a = fabsf(v);
+    const float y0 = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(a) * 0.3333333432674407958984375f);
+    const float r = __builtin_amdgcn_rcpf(y0 * y0);
+    const float y = fmaf(a * r, 0.3333333432674407958984375f, y0 * 0.666666686534881591796875f);
+    return copysignf((y0 == 0.0f || y0 == __builtin_inff()) ? y0 : y, v);
+}
+__device__ __forceinline__ double epi_cbrt(double v) { return cbrt(v); }
+__device__ __forceinline__ float epi_pow(float v, float p)
+{
+    const float l0 = __builtin_amdgcn_logf(v);                        // NaN for v < 0, as pow with a fractional p
+    const float r = v * __builtin_amdgcn_exp2f(-l0);                  // 1 + eps
+    const float corr = (r - 1.0f) * 1.44269502162933349609375f;       // log2(1 + eps)
+    const float eh = p * l0;
+    const float el = fmaf(p, l0, -eh) + p * corr;
+    const float yh = __builtin_amdgcn_exp2f(eh);
+    const float y = fmaf(yh * 0.693147182464599609375f, el, yh);
+    return (v == 0.0f || fabsf(l0) == __builtin_inff()) ? ((v == 0.0f) ? 0.0f : v) : y;
+}
+__device__ __forceinline__ double epi_pow(double v, double p) { return pow(v, p); }
 
 // epilogue of the power value (reference c/stft.c:86-95, then c/pow_compress.c:28-47)
 template <typename T>
@@ -78,10 +104,45 @@ __device__ __forceinline__ T power_epilogue(T v, const Epilogue &e)
         v += (T)e.preg;
         if (e.pc == 2) { v = epi_log(v); }
         else if (e.pc == 3) { v = epi_sqrt(v); }
-        else if (e.pc == 4) { v = cbrt(v); }
-        else if (e.pc == 5) { v = pow(v, (T)e.p); }
+        else if (e.pc == 4) { v = epi_cbrt(v); }
+        else if (e.pc == 5) { v = epi_pow(v, (T)e.p); }
     }
     return v;
+}
+
+// the same for N values of a lane, with the (uniform) branches outside the loops over the values: per value
+// they cost the 512-point kernel more than the arithmetic they select
+template <typename T, int N>
+__device__ __forceinline__ void power_epilogue_n(T (&v)[N], const Epilogue &e)
+{
+    if (e.amp) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) { v[i] = epi_sqrt(v[i]); }
+    }
+    if (e.lg) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) { v[i] = epi_log(v[i]); }
+    }
+    if (e.pc) {
+        const T preg = (T)e.preg;
+        if (e.pc == 1) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) { v[i] += preg; }
+        } else if (e.pc == 2) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) { v[i] = epi_log(v[i] + preg); }
+        } else if (e.pc == 3) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) { v[i] = epi_sqrt(v[i] + preg); }
+        } else if (e.pc == 4) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) { v[i] = epi_cbrt(v[i] + preg); }
+        } else {
+            const T p = (T)e.p;
+#pragma unroll
+            for (int i = 0; i < N; ++i) { v[i] = epi_pow(v[i] + preg, p); }
+        }
+    }
 }
 
 template <typename T> struct vec2;

@@ -1,0 +1,38 @@
+#!/bin/bash
+# rocprofv3 evidence: kernel-trace stats for the three workloads, then FETCH_SIZE and WRITE_SIZE in passes of their own
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/prof_r01c
+rm -rf $O; mkdir -p $O
+cd $R
+W3=flt_f64_8ch_x_1h16k_povey400_hop160_nfft512
+W4=longwin_f32_8ch_x_1h48k_bh4096_hop1024_nfft4096
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err || exit 1
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --ramp-ms 0 --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/pmc_fetch.err || exit 1
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --ramp-ms 0 --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/pmc_write.err || exit 1
+for w in $W3 $W4; do
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$w -- python3 bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_$w.json 2> $O/stats_$w.err || exit 1
+  timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$w -- python3 bench.py --workload $w --ramp-ms 0 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/pmc_fetch_$w.err || exit 1
+  timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$w -- python3 bench.py --workload $w --ramp-ms 0 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/pmc_write_$w.err || exit 1
+done
+timeout -k 10 200 python3 bench.py --steps 50 --warmup 10 > $O/bench_plain.json 2> $O/bench_plain.err
+python3 - <<PY
+import csv,glob,collections,json
+O='$O'
+out={}
+def stats(d):
+    st=glob.glob(O+'/'+d+'/**/*kernel_stats.csv',recursive=True)
+    return [r for r in csv.DictReader(open(st[0])) if 'stft' in r['Name']]
+def pmc(d):
+    f=glob.glob(O+'/'+d+'/**/*counter_collection.csv',recursive=True)[0]
+    agg=collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if 'stft' in r['Kernel_Name']: agg[r['Counter_Name']].append(float(r['Counter_Value']))
+    return {k+'_per_launch':sum(v)/len(v) for k,v in agg.items()}
+out['utt1024x10s_f32_hann400_hop160_nfft512']={'kernel_stats':stats('stats'),**pmc('pmc_fetch'),**pmc('pmc_write')}
+for w in ('$W3','$W4'):
+    out[w]={'kernel_stats':stats('stats_'+w),**pmc('pmc_fetch_'+w),**pmc('pmc_write_'+w)}
+json.dump(out,open(O+'/summary.json','w'),indent=1)
+for k,v in out.items(): print(k, v['kernel_stats'][0]['AverageNs'], v.get('FETCH_SIZE_per_launch'), v.get('WRITE_SIZE_per_launch'))
+PY
+cat $O/bench_plain.json

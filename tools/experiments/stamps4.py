@@ -1,0 +1,24 @@
+import os, sys, ctypes as C
+sys.path.insert(0, '.')
+import numpy as np, torch, dsp_amd
+B, N = 8, 172800000 // 4
+x = torch.randn((B, N), device='cuda') * 0.1
+win = torch.from_numpy(dsp_amd.blackmanharris(4096)).cuda()
+y = dsp_amd.stft_dev(x, win, 1024, nfft=4096)
+for _ in range(60): dsp_amd.stft_dev(x, win, 1024, nfft=4096, out=y)
+torch.cuda.synchronize()
+buf = np.zeros(2048 * 8, dtype=np.uint64)
+h = C.CDLL(os.environ['DSP_AMD_LIB'])
+rc = h.dsp_debug_read_stamps4096(buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.size))
+a = buf.reshape(2048, 8).astype(np.float64)
+tot = a.sum(1)
+frames = y.shape[0] * y.shape[1] / 2048
+names = ['dft16x2+combine', 'tw+swap+write+sync+locate+early', 'p2 read+dft32', 'sync+zwrite+sync', 'late loads issue', 'split+stores', 'window (wait for loads)', 'shift+issue loads']
+print('rc', rc, 'mean total cycles per wave', tot.mean(), 'frames/wave', frames)
+for i, n in enumerate(names):
+    print(f'{n:32s} {a[:, i].mean() / frames:9.0f} cyc/frame  {100 * a[:, i].mean() / tot.mean():5.1f}%')
+print('total per wave: min %.0f  p50 %.0f  p90 %.0f  max %.0f' % (tot.min(), np.percentile(tot, 50), np.percentile(tot, 90), tot.max()))
+w = tot.reshape(256, 8)
+print('per xcd mean/max:', [(int(w[x::8].mean()), int(w[x::8].max())) for x in range(8)])
+print('mean by wave slot:', [int(v) for v in w.mean(0)])
+print('std across WGs of WG-mean: %.0f ; mean within-WG std: %.0f' % (w.mean(1).std(), w.std(1).mean()))

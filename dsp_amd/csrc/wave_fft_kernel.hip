@@ -29,10 +29,6 @@ __host__ __device__ constexpr int wpad(int i) { return i + (i >> 4); }
 constexpr int wave_cap(int M, int elem) { return M / 64 < 4 ? 4 : (M / 64 > (elem == 4 ? 16 : 8) ? (elem == 4 ? 16 : 8) : M / 64); }
 constexpr int wave_radix(int rem, int cap) { return rem < cap ? rem : cap; }
 constexpr int wave_slots(int M) { return wpad(M) + 1; }
-// waves per CU worth having: the kernels wait on LDS round trips more than they compute, so as many as the
-// registers allow: 16 for the short transforms, 12 above (measured, nfft 256: 0.92 ms at 8 waves, 0.59 at
-// 16; nfft 1024 at 129 registers: 1.07 ms at 8, 0.82 at 12, 1.18 at 14 in two workgroups of 7)
-constexpr int wave_target(int M) { return M <= 256 ? 16 : 12; }
 // Pass twiddles: the pass that starts at sub-transform length ns (radix R) multiplies input t of butterfly
 // j by W_{ns R}^{k t}, k = j mod ns.  They are laid out per pass as [t - 1][k], so that the lanes of a wave
 // read consecutive entries at a compile-time offset.  Offset of the pass that starts at ns_target (the
@@ -47,9 +43,18 @@ constexpr int wave_tw_off(int M, int elem, int ns_target)
     }
     return off;
 }
+// A pass can work in place (all reads of the wave, a fence, then the writes): one buffer per wave instead
+// of two, i.e. twice the waves per CU for the LDS, but no overlap of a pass's reads and writes.  It pays
+// where the LDS limits the waves and the registers allow more: float32 nfft 512 and 1024 (nfft 1024: 0.80 -> 0.70 ms at 16
+// waves per CU; nfft 2048 float32 0.76 -> 0.86 and nfft 1024 float64 1.73 -> 1.99 with it: kept out).
+constexpr bool wave_inplace(int M, int elem) { return elem == 4 && M / 64 >= 4 && M / 64 <= 8; }
+// waves per CU worth having: the kernels wait on LDS round trips more than they compute, so as many as the
+// registers allow: 16 for the short transforms and the in-place ones, 12 above (measured, nfft 256: 0.92 ms at 8 waves, 0.59 at
+// 16; nfft 1024 at 129 registers: 1.07 ms at 8, 0.82 at 12, 1.18 at 14 in two workgroups of 7)
+constexpr int wave_target(int M, int elem) { return (M <= 256 || wave_inplace(M, elem)) ? 16 : 12; }
 // LDS of a workgroup of wpw waves: W_nfft^k, k < M, for the split; the pass twiddles; the window (M
-// pairs); two buffers per wave
-constexpr long wave_lds_of(int M, int elem, int wpw) { return (2L * M + wave_tw_off(M, elem, M) + 2L * wave_slots(M) * wpw) * 2 * elem; }
+// pairs); one or two buffers per wave
+constexpr long wave_lds_of(int M, int elem, int wpw) { return (2L * M + wave_tw_off(M, elem, M) + (wave_inplace(M, elem) ? 1L : 2L) * wave_slots(M) * wpw) * 2 * elem; }
 // waves per workgroup (1..8): the smallest count that puts the most waves (up to wave_target) on a CU's
 // 160 KB; 0: the buffers do not fit at all
 constexpr int wave_wpw(int M, int elem)
@@ -59,7 +64,7 @@ constexpr int wave_wpw(int M, int elem)
         const long lds = wave_lds_of(M, elem, wpw);
         if (lds > 160 * 1024) { break; }
         long waves = (160 * 1024 / lds) * wpw;
-        if (waves > wave_target(M)) { waves = wave_target(M); }
+        if (waves > wave_target(M, elem)) { waves = wave_target(M, elem); }
         if (waves > best_waves) { best_waves = (int)waves; best = wpw; }
     }
     return best;
@@ -119,6 +124,50 @@ __device__ __forceinline__ void wave_pass(const cx<T> *src, cx<T> *dst, const cx
     }
 }
 
+// The same pass in place: every lane first reads the inputs of all its butterflies, then, behind a wave
+// fence, transforms and writes them.
+template <typename T, int M, int R, int NS>
+__device__ __forceinline__ void wave_pass_inplace(cx<T> *buf, const cx<T> *tw, const int lane)
+{
+    using C = cx<T>;
+    constexpr int NB = M / R;
+    constexpr int IT = NB >= 64 ? NB / 64 : 1;
+    constexpr int OFF = wave_tw_off(M, (int)sizeof(T), NS);
+    const bool active = NB >= 64 || lane < NB;
+    C v[IT][R];
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+#pragma unroll
+            for (int t = 0; t < R; ++t) { v[i][t] = buf[wpad(lane + 64 * i + t * NB)]; }
+        }
+    }
+    wave_sync();
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int j = lane + 64 * i;
+            const int k = j & (NS - 1);
+            if (NS > 1) {
+#pragma unroll
+                for (int t = 1; t < R; ++t) { v[i][t] = cx_mul<T>(v[i][t], tw[OFF + (t - 1) * NS + k]); }
+            }
+            const int base = (j - k) * R + k;
+            if constexpr (R == 16) {
+                dft16c<T, 16>(v[i]);
+#pragma unroll
+                for (int t = 0; t < 16; ++t) { buf[wpad(base + t * NS)] = v[i][slot16(t)]; }
+            } else {
+                if constexpr (R == 8) { dft8c<T>(v[i]); }
+                else if constexpr (R == 4) { dft4c<T>(v[i][0], v[i][1], v[i][2], v[i][3]); }
+                else { const C a = v[i][0], b = v[i][1]; v[i][0] = a + b; v[i][1] = a - b; }
+#pragma unroll
+                for (int t = 0; t < R; ++t) { buf[wpad(base + t * NS)] = v[i][t]; }
+            }
+        }
+    }
+}
+
 // the pass twiddles from sub-transform length NS on, from the table W_2M^m, m < M, in global memory
 template <typename T, int M, int NS>
 __device__ __forceinline__ void wave_fill_tw(cx<T> *ptw, const T *__restrict__ tw, const int tid, const int nthr)
@@ -148,9 +197,15 @@ __device__ __forceinline__ cx<T> *wave_passes(cx<T> *src, cx<T> *dst, const cx<T
         return src;
     } else {
         constexpr int R = wave_radix(M / NS, wave_cap(M, (int)sizeof(T)));
-        wave_pass<T, M, R, NS>(src, dst, tw, lane);
-        wave_sync();
-        return wave_passes<T, M, NS * R>(dst, src, tw, lane);
+        if constexpr (wave_inplace(M, (int)sizeof(T))) {
+            wave_pass_inplace<T, M, R, NS>(src, tw, lane);
+            wave_sync();
+            return wave_passes<T, M, NS * R>(src, dst, tw, lane);
+        } else {
+            wave_pass<T, M, R, NS>(src, dst, tw, lane);
+            wave_sync();
+            return wave_passes<T, M, NS * R>(dst, src, tw, lane);
+        }
     }
 }
 
@@ -177,8 +232,9 @@ __global__ __launch_bounds__(64 * wave_wpw(NFFT / 2, (int)sizeof(T)), 2) void st
     C *twl = reinterpret_cast<C *>(smem_raw);
     C *ptw = twl + M;
     C *wl = ptw + TWN;
-    C *buf0 = wl + M + (size_t)wv * 2 * SLOTS;
-    C *buf1 = buf0 + SLOTS;
+    constexpr int NBUF = wave_inplace(M, (int)sizeof(T)) ? 1 : 2;
+    C *buf0 = wl + M + (size_t)wv * NBUF * SLOTS;
+    C *buf1 = buf0 + (NBUF - 1) * SLOTS;
     for (int m = tid; m < M; m += 64 * WPW) {
         twl[m] = cx_make<T>(tw[2 * m], tw[2 * m + 1]);
         wl[m] = cx_make<T>(2 * m < L ? win[2 * m] : T(0), 2 * m + 1 < L ? win[2 * m + 1] : T(0));
@@ -309,7 +365,7 @@ static hipError_t launch_wave_inst(T *Y, const T *X, const T *win, const T *tw, 
     static LdsGrant grant;
     if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_wave_kernel<T, NFFT>), lds, grant); e != hipSuccess) { return e; }
     const long long total = (long long)d.B * d.W;
-    const long long per_cu = std::max<long long>(1, std::min<long long>(wave_target(M) / WPW > 0 ? wave_target(M) / WPW : 1, (long long)(160 * 1024 / lds)));   // resident workgroups per CU
+    const long long per_cu = std::max<long long>(1, std::min<long long>(wave_target(M, (int)sizeof(T)) / WPW > 0 ? wave_target(M, (int)sizeof(T)) / WPW : 1, (long long)(160 * 1024 / lds)));   // resident workgroups per CU
     long long grid = (total + WPW - 1) / WPW;
     grid = std::min(grid, 256 * per_cu);
     hipLaunchKernelGGL((stft_wave_kernel<T, NFFT>), dim3((unsigned)grid), dim3(64 * WPW), lds, s, Y, X, win, tw, d);

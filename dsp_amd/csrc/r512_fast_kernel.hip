@@ -47,6 +47,9 @@ __device__ __forceinline__ double dpp_partner16(double v)
 template <typename T> struct vec16;                   // 16-byte vector of T
 template <> struct vec16<float> { using type = float4; static constexpr int n = 4; };
 template <> struct vec16<double> { using type = double2; static constexpr int n = 2; };
+template <typename T> struct vec16u;                  // the same at element alignment
+template <> struct vec16u<float> { typedef float type __attribute__((ext_vector_type(4), aligned(4))); };
+template <> struct vec16u<double> { typedef double type __attribute__((ext_vector_type(2), aligned(8))); };
 
 #ifndef R512F_TW_LDS
 #define R512F_TW_LDS 0          // 1: pass-1 twiddles come from an LDS table instead of 30 registers
@@ -180,6 +183,16 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
                 if (a.N == -12345)
 #endif
                 pre[q] = reinterpret_cast<const TV *>(src)[min(q * 64 + lane, nvec - 1)];
+            }
+        } else if (inside) {
+            // a span that does not start on a 16-byte boundary (odd ss0, a hop that is no multiple of 4
+            // elements, an unaligned signal): the same loads at element alignment
+            using TVu = typename vec16u<T>::type;
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                const TVu v = reinterpret_cast<const TVu *>(src)[min(q * 64 + lane, nvec - 1)];
+                if constexpr (VEC == 4) { pre[q] = TV{v.x, v.y, v.z, v.w}; }
+                else { pre[q] = TV{v.x, v.y}; }
             }
         } else {
             FrameDesc d{};

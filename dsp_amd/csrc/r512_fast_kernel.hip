@@ -1,4 +1,4 @@
-// Fast path of the 512-point fused STFT kernel for gfx950: integer hop with 3*hop + 512 <= 1024,
+// Fast path of the 512-point fused STFT kernel for gfx950: integer hop with 3*hop + 512 <= 1280 (hop <= 256),
 // even hop, frames addressed as start = ss0 + w*hop (the stft framing, and the stft_flt framing when
 // its hop is integral).  Same arithmetic as the basic kernel in r512_kernel.hip; what differs is the
 // schedule around it:
@@ -109,14 +109,15 @@ __device__ unsigned long long g_r512f_stamps[8192 * 8];
 #define R512F_MINWAVES_F32 2
 #endif
 
-template <typename T, int NR, bool MN0, bool EPI>
+template <typename T, int NR, bool MN0, bool EPI, bool WIDE>
 __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) void stft_r512_fast_kernel(T *__restrict__ Y, const T *__restrict__ X,
                                                               const T *__restrict__ win, const T *__restrict__ tw,
                                                               const R512FastArgs a)
 {
     using T2 = typename vec2<T>::type;
     using TV = typename vec16<T>::type;
-    constexpr int VEC = vec16<T>::n, NV = 16 / VEC;        // 16 staged elements per lane
+    // staged elements per lane: 16 (spans of up to 1024 samples: hop <= 170), WIDE: 20 (1280: hop <= 256)
+    constexpr int VEC = vec16<T>::n, SPAN = WIDE ? 1280 : 1024, NV = SPAN / 64 / VEC;
     constexpr bool WINREG = (sizeof(T) == 4) && !R512F_WIN_LDS;
     constexpr bool TWREG = !R512F_TW_LDS && !(R512F_TW_LDS_F64 && sizeof(T) == 8);
     constexpr int M = 256, F = 257;
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
     auto load_span = [&](const T *xb, const int w) {
         const int s0 = a.ss0 + w * a.stp;
         const T *src = xb + (s0 - (a.edge ? a.rd_shift : 0));
-        const bool inside = s0 >= 0 && s0 + 1024 <= a.N && (a.edge == 0 || s0 >= a.rd_shift);
+        const bool inside = s0 >= 0 && s0 + SPAN <= a.N && (a.edge == 0 || s0 >= a.rd_shift);
         if (inside && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
 #pragma unroll
             for (int q = 0; q < NV; ++q) {
@@ -463,26 +464,26 @@ extern "C" int dsp_debug_read_stamps(unsigned long long *dst, size_t n)
 }
 #endif
 
-// Conditions of the fast path: frames at ss0 + w*hop, hop even with 3*hop + 512 <= 1024, and every
+// Conditions of the fast path: frames at ss0 + w*hop, hop even with 3*hop + 512 <= 1280, and every
 // index of one signal's input and output fits 31 bits.
 bool r512_fast_supported(const FrameDesc &d)
 {
-    return d.tbl == nullptr && d.nfft == 512 && d.L >= 1 && d.L <= 512 && !(d.stp & 1) && 3ll * d.stp + 512 <= 1024 &&
+    return d.tbl == nullptr && d.nfft == 512 && d.L >= 1 && d.L <= 512 && !(d.stp & 1) && 3ll * d.stp + 512 <= 1280 &&
            d.N < (1ll << 31) - 4096 && (long long)d.W * 257 < (1ll << 30) && (long long)d.B * ((d.W + 3) / 4) < (1ll << 30) && d.ss0 > -(1ll << 30) && d.ss0 < (1ll << 30) &&
            d.rd_shift >= 0 && d.rd_shift < (1ll << 30);
 }
 
-template <typename T, int NR, bool MN0, bool EPI>
+template <typename T, int NR, bool MN0, bool EPI, bool WIDE>
 static hipError_t launch_fast_inst(T *Y, const T *X, const T *win, const T *tw, const R512FastArgs &a, hipStream_t s)
 {
     const size_t lds = (4 * (size_t)R512F_WAVE_ELEMS + 512 + 512) * sizeof(T);
     static LdsGrant grant;
-    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r512_fast_kernel<T, NR, MN0, EPI>), lds, grant); e != hipSuccess) { return e; }
+    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r512_fast_kernel<T, NR, MN0, EPI, WIDE>), lds, grant); e != hipSuccess) { return e; }
     static const int wgs_per_cu = [] { const char *e = getenv("DSP_R512F_WGS_PER_CU"); return e ? atoi(e) : 2; }();
     long long grid = ((long long)a.steps + 3) / 4;
     if (grid > 256ll * wgs_per_cu) { grid = 256ll * wgs_per_cu; }
     grid = (grid + 7) & ~7ll;                           // whole groups of 8 workgroups (one per XCD)
-    hipLaunchKernelGGL((stft_r512_fast_kernel<T, NR, MN0, EPI>), dim3((unsigned)grid), dim3(256), lds, s, Y, X, win, tw, a);
+    hipLaunchKernelGGL((stft_r512_fast_kernel<T, NR, MN0, EPI, WIDE>), dim3((unsigned)grid), dim3(256), lds, s, Y, X, win, tw, a);
     return hipGetLastError();
 }
 
@@ -495,8 +496,14 @@ hipError_t launch_stft_r512_fast(T *Y, const T *X, const T *win, const T *tw, co
     a.sps = (d.W + 3) / 4;
     a.steps = d.B * a.sps;
     const bool epi = d.epi.any();
-    const bool nr13 = d.L > 384 && d.L <= 416;
-#define DSP_R512F(NR_, MN0_, EPI_) launch_fast_inst<T, NR_, MN0_, EPI_>(Y, X, win, tw, a, s)
+    const bool wide = 3 * d.stp + 512 > 1024;            // spans of more than 1024 samples: 20 staged elements per lane
+    const bool nr13 = d.L > 384 && d.L <= 416 && !wide;
+#define DSP_R512F(NR_, MN0_, EPI_) launch_fast_inst<T, NR_, MN0_, EPI_, false>(Y, X, win, tw, a, s)
+#define DSP_R512W(MN0_, EPI_) launch_fast_inst<T, 16, MN0_, EPI_, true>(Y, X, win, tw, a, s)
+    if (wide) {
+        if (d.mn0) { return epi ? DSP_R512W(true, true) : DSP_R512W(true, false); }
+        return epi ? DSP_R512W(false, true) : DSP_R512W(false, false);
+    }
     if (nr13) {
         if (d.mn0) { return epi ? DSP_R512F(13, true, true) : DSP_R512F(13, true, false); }
         return epi ? DSP_R512F(13, false, true) : DSP_R512F(13, false, false);
@@ -504,6 +511,7 @@ hipError_t launch_stft_r512_fast(T *Y, const T *X, const T *win, const T *tw, co
     if (d.mn0) { return epi ? DSP_R512F(16, true, true) : DSP_R512F(16, true, false); }
     return epi ? DSP_R512F(16, false, true) : DSP_R512F(16, false, false);
 #undef DSP_R512F
+#undef DSP_R512W
 }
 
 template hipError_t launch_stft_r512_fast<float>(float *, const float *, const float *, const float *, const FrameDesc &, hipStream_t);

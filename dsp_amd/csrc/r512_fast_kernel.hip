@@ -1,5 +1,5 @@
 // Fast path of the 512-point fused STFT kernel for gfx950: integer hop with 3*hop + 512 <= 1280 (hop <= 256),
-// even hop, frames addressed as start = ss0 + w*hop (the stft framing, and the stft_flt framing when
+// frames addressed as start = ss0 + w*hop (the stft framing, and the stft_flt framing when
 // its hop is integral).  Same arithmetic as the basic kernel in r512_kernel.hip; what differs is the
 // schedule around it:
 //   * the span of the next 4 frames is fetched from HBM into registers (16-byte loads) while the
@@ -47,6 +47,9 @@ __device__ __forceinline__ double dpp_partner16(double v)
 template <typename T> struct vec16;                   // 16-byte vector of T
 template <> struct vec16<float> { using type = float4; static constexpr int n = 4; };
 template <> struct vec16<double> { using type = double2; static constexpr int n = 2; };
+template <typename T> struct vec2e;                   // a pair of T at element alignment
+template <> struct vec2e<float> { typedef float type __attribute__((ext_vector_type(2), aligned(4))); };
+template <> struct vec2e<double> { typedef double type __attribute__((ext_vector_type(2), aligned(8))); };
 template <typename T> struct vec16u;                  // the same at element alignment
 template <> struct vec16u<float> { typedef float type __attribute__((ext_vector_type(4), aligned(4))); };
 template <> struct vec16u<double> { typedef double type __attribute__((ext_vector_type(2), aligned(8))); };
@@ -278,8 +281,16 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
             if (n1 < NR) {
-                const T2 t = *reinterpret_cast<const T2 *>(xrow + 32 * n1);
-                C v = C{t.x, t.y};
+                C v;
+                if constexpr (WIDE) {
+                    // odd hops put the rows of frames 1 and 3 at odd element offsets: pair reads at element alignment
+                    using T2e = typename vec2e<T>::type;
+                    const T2e t = *reinterpret_cast<const T2e *>(xrow + 32 * n1);
+                    v = C{t.x, t.y};
+                } else {
+                    const T2 t = *reinterpret_cast<const T2 *>(xrow + 32 * n1);
+                    v = C{t.x, t.y};
+                }
                 if (NR == 16 || n1 == NR - 1) {          // rows that may reach past the window
                     const int l = 32 * n1 + 2 * j;
                     v.x = (l < L) ? v.x : T(0);
@@ -464,11 +475,11 @@ extern "C" int dsp_debug_read_stamps(unsigned long long *dst, size_t n)
 }
 #endif
 
-// Conditions of the fast path: frames at ss0 + w*hop, hop even with 3*hop + 512 <= 1280, and every
+// Conditions of the fast path: frames at ss0 + w*hop with 3*hop + 512 <= 1280, and every
 // index of one signal's input and output fits 31 bits.
 bool r512_fast_supported(const FrameDesc &d)
 {
-    return d.tbl == nullptr && d.nfft == 512 && d.L >= 1 && d.L <= 512 && !(d.stp & 1) && 3ll * d.stp + 512 <= 1280 &&
+    return d.tbl == nullptr && d.nfft == 512 && d.L >= 1 && d.L <= 512 && 3ll * d.stp + 512 <= 1280 &&
            d.N < (1ll << 31) - 4096 && (long long)d.W * 257 < (1ll << 30) && (long long)d.B * ((d.W + 3) / 4) < (1ll << 30) && d.ss0 > -(1ll << 30) && d.ss0 < (1ll << 30) &&
            d.rd_shift >= 0 && d.rd_shift < (1ll << 30);
 }
@@ -496,7 +507,7 @@ hipError_t launch_stft_r512_fast(T *Y, const T *X, const T *win, const T *tw, co
     a.sps = (d.W + 3) / 4;
     a.steps = d.B * a.sps;
     const bool epi = d.epi.any();
-    const bool wide = 3 * d.stp + 512 > 1024;            // spans of more than 1024 samples: 20 staged elements per lane
+    const bool wide = 3 * d.stp + 512 > 1024 || (d.stp & 1);   // spans of more than 1024 samples (20 staged elements per lane), odd hops
     const bool nr13 = d.L > 384 && d.L <= 416 && !wide;
 #define DSP_R512F(NR_, MN0_, EPI_) launch_fast_inst<T, NR_, MN0_, EPI_, false>(Y, X, win, tw, a, s)
 #define DSP_R512W(MN0_, EPI_) launch_fast_inst<T, 16, MN0_, EPI_, true>(Y, X, win, tw, a, s)

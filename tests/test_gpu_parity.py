@@ -103,7 +103,8 @@ def test_both_512_families_agree_with_oracle(O, D, dt):
     a hop above the span-staging limit, an odd hop, frame starts that are not 16-byte aligned)."""
     for (N, L, stp) in [(7013, 400, 160), (7013, 512, 33), (30000, 320, 1500), (1900, 400, 160), (700, 400, 160),
                         (9001, 400, 170), (9001, 402, 160), (9001, 399, 166),    # spans that start off 16-byte boundaries
-                        (9001, 512, 256), (9001, 400, 200), (5000, 512, 172), (9001, 300, 254)]:   # spans of 1028 to 1280 samples
+                        (9001, 512, 256), (9001, 400, 200), (5000, 512, 172), (9001, 300, 254),   # spans of 1028 to 1280 samples
+                        (9001, 400, 161), (9001, 512, 255), (2000, 100, 1), (9001, 401, 257)]:   # odd hops; 257: above the limit
         x = signal(N, N, dt)
         win = D.povey(L, dt)
         rc, Yref = O.stft(x, win, stp, 512, 0)

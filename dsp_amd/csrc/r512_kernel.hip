@@ -72,17 +72,64 @@ __global__ __launch_bounds__(256) void stft_r512_kernel(T *__restrict__ Y, const
                 const int need = 3 * d.stp + 512;
                 if (s0 >= 0 && s0 + need <= d.N && (d.edge == 0 || s0 >= d.rd_shift)) {
                     const T *src = xb + (s0 - (d.edge ? d.rd_shift : 0));
-                    for (int i = lane; i < need; i += 64) { xs[i] = src[i]; }
+                    constexpr int SB = sizeof(T) == 4 ? 8 : 4;     // loads per lane in flight at a time
+                    for (int i0 = 0; i0 < need; i0 += 64 * SB) {
+                        T t[SB];
+#pragma unroll
+                        for (int q = 0; q < SB; ++q) { const int i = i0 + 64 * q + lane; t[q] = (i < need) ? src[i] : T(0); }
+#pragma unroll
+                        for (int q = 0; q < SB; ++q) { const int i = i0 + 64 * q + lane; if (i < need) { xs[i] = t[q]; } }
+                    }
                 } else {
                     for (int i = lane; i < need; i += 64) { xs[i] = fetch_sample(xb, d, s0, d.rd_shift, i); }
                 }
             } else {
-                for (int g = 0; g < 4; ++g) {
-                    if (w + g < d.W) {
-                        long long ss, rdoff;
-                        frame_origin(d, w + g, ss, rdoff);
-                        for (int l = lane; l < 512; l += 64) {
-                            xs[g * 512 + l] = (l < L) ? fetch_sample(xb, d, ss, rdoff, l) : T(0);
+                // frame starts: from the table with one load for the 4 frames (lane g: start, lane 4 + g:
+                // read position), or from the hop
+                long long ssg[4], rdg[4];
+                if (d.tbl) {
+                    const int fr = w + (lane & 3);
+                    const int v = (fr < d.W) ? d.tbl[2 * fr + ((lane >> 2) & 1)] : 0;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int sv = __shfl(v, g), rv = __shfl(v, 4 + g);
+                        ssg[g] = sv; rdg[g] = (long long)sv - rv;
+                    }
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) { frame_origin(d, min(w + g, d.W - 1), ssg[g], rdg[g]); }
+                }
+                // frames inside their signal: the loads of GB frames (8 per lane and frame) go out before the
+                // first is stored (as many as the registers take); the others sample by sample through the
+                // edge rule
+                constexpr int GB = sizeof(T) == 4 ? 2 : 1;
+#pragma unroll
+                for (int g0 = 0; g0 < 4; g0 += GB) {
+                    T v[GB][8];
+                    bool in[GB];
+#pragma unroll
+                    for (int gg = 0; gg < GB; ++gg) {
+                        const int g = g0 + gg;
+                        in[gg] = w + g < d.W && ssg[g] >= 0 && ssg[g] + L <= d.N && (d.edge == 0 || ssg[g] >= rdg[g]);
+                        if (in[gg]) {
+                            const T *src = xb + (ssg[g] - (d.edge ? rdg[g] : 0));
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const int l = lane + 64 * q;
+                                v[gg][q] = (l < L) ? src[l] : T(0);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int gg = 0; gg < GB; ++gg) {
+                        const int g = g0 + gg;
+                        if (in[gg]) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) { xs[g * 512 + lane + 64 * q] = v[gg][q]; }
+                        } else if (w + g < d.W) {
+                            for (int l = lane; l < 512; l += 64) {
+                                xs[g * 512 + l] = (l < L) ? fetch_sample(xb, d, ssg[g], rdg[g], l) : T(0);
+                            }
                         }
                     }
                 }

@@ -249,6 +249,31 @@ def test_stft_flt_matches_oracle(O, D, dt, intended):
         D.set_flt_mode(False)
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_stft_flt_other_sizes(O, D, dt):
+    """stft_flt on the transform lengths of the wavefront-per-frame kernels and of the generic one: integral
+    and non-integral hops (start tables), frames off both edges, both framing modes, both families."""
+    x = signal(23, 9000, dt)
+    for intended in (False, True):
+        D.set_flt_mode(intended)
+        try:
+            for (L, nfft, c0, stp, W, flags) in [(200, 256, 100.0, 80.0, 60, (0, 0, 0)), (200, 256, -300.0, 80.5, 120, (1, 0, 0)),
+                                                 (1000, 1024, 500.0, 250.0, 30, (0, 1, 0)), (1000, 1024, 17.0, 333.3, 40, (1, 1, 1)),
+                                                 (64, 64, 8000.0, 33.0, 40, (0, 0, 0)), (2048, 2048, 1024.0, 512.0, 14, (0, 0, 1))]:
+                win = D.povey(L, dt)
+                rc, Yref = O.stft_flt(x, win, W, c0, stp, nfft, *flags, intended=intended)
+                assert rc == 0
+                for generic in (False, True):
+                    D.force_generic(generic)
+                    try:
+                        Y = D.stft_flt(x, win, W, c0, stp, *[bool(f) for f in flags], nfft=nfft)
+                    finally:
+                        D.force_generic(False)
+                    check_spec(O, Y, Yref, flags[1], flags[2])
+        finally:
+            D.set_flt_mode(False)
+
+
 @pytest.mark.parametrize("tag", ["s", "d"])
 def test_stft_flt_intended_against_reference_fixtures(O, D, tag):
     g = load_golden(f"ref_flt_{tag}.npz")

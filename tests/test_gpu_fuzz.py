@@ -1,0 +1,75 @@
+"""Seeded random shapes through every kernel family against the oracle: transform lengths from 16 to 4096,
+any window length up to nfft, any hop (odd, above the window, above the span limits), signals shorter than a
+window, every flag, snipped edges, and stft_flt with integral and fractional hops in both framing modes."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import check_spec, signal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def D():
+    import dsp_amd
+    return dsp_amd
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_random_shapes_stft(O, D, dt):
+    rng = np.random.default_rng(20240 + np.dtype(dt).itemsize)
+    for it in range(600):
+        nfft = int(2 ** rng.integers(4, 13))
+        L = int(rng.integers(1, nfft + 1)) if rng.random() < 0.6 else nfft
+        stp = int(rng.integers(1, 2 * L + 2)) if rng.random() < 0.7 else max(1, L // int(rng.integers(2, 6)))
+        N = int(rng.integers(1, 12 * L + 40))
+        if N * nfft // max(stp, 1) > 3_000_000:           # keep the oracle's double DFT in seconds
+            stp = max(stp, N * nfft // 3_000_000 + 1)
+        snip = bool(rng.integers(0, 2)) and L <= N
+        flags = tuple(int(v) for v in rng.integers(0, 2, 3))
+        x = signal(1000 + it, N, dt) + dt(0.05)
+        win = D.povey(L, dt) if L > 1 else np.ones(1, dt)
+        rc, Yref = O.stft(x, win, stp, nfft, snip, *flags)
+        assert rc == 0, (nfft, L, stp, N, snip, flags)
+        for generic in (False, True):
+            D.force_generic(generic)
+            try:
+                Y = D.stft(x, win, stp, snip, *[bool(f) for f in flags], nfft=nfft)
+            finally:
+                D.force_generic(False)
+            try:
+                check_spec(O, Y, Yref, flags[1], flags[2])
+            except AssertionError as e:
+                raise AssertionError(f"nfft {nfft} L {L} stp {stp} N {N} snip {snip} flags {flags} generic {generic}: {e}")
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_random_shapes_stft_flt(O, D, dt):
+    rng = np.random.default_rng(777 + np.dtype(dt).itemsize)
+    for it in range(400):
+        nfft = int(2 ** rng.integers(4, 13))
+        L = int(rng.integers(1, nfft + 1)) if rng.random() < 0.6 else nfft
+        N = int(rng.integers(L + 1, 10 * L + 60))
+        stp = float(rng.integers(1, L + 2)) if rng.random() < 0.5 else float(rng.uniform(0.5, 1.5 * L))
+        W = int(min(N, rng.integers(1, 40)))
+        c0 = float(rng.uniform(-1.5 * L, N - 1))
+        flags = tuple(int(v) for v in rng.integers(0, 2, 3))
+        intended = bool(rng.integers(0, 2))
+        x = signal(5000 + it, N, dt) + dt(0.05)
+        win = D.povey(L, dt) if L > 1 else np.ones(1, dt)
+        D.set_flt_mode(intended)
+        try:
+            rc, Yref = O.stft_flt(x, win, W, c0, stp, nfft, *flags, intended=intended)
+            assert rc == 0, (nfft, L, stp, N, W, c0)
+            for generic in (False, True):
+                D.force_generic(generic)
+                try:
+                    Y = D.stft_flt(x, win, W, c0, stp, *[bool(f) for f in flags], nfft=nfft)
+                finally:
+                    D.force_generic(False)
+                try:
+                    check_spec(O, Y, Yref, flags[1], flags[2])
+                except AssertionError as e:
+                    raise AssertionError(f"nfft {nfft} L {L} stp {stp} N {N} W {W} c0 {c0} flags {flags} intended {intended} generic {generic}: {e}")
+        finally:
+            D.set_flt_mode(False)

@@ -28,6 +28,9 @@ __host__ __device__ constexpr int wpad(int i) { return i + (i >> 4); }
 
 constexpr int wave_cap(int M, int elem) { return M / 64 < 4 ? 4 : (M / 64 > (elem == 4 ? 16 : 8) ? (elem == 4 ? 16 : 8) : M / 64); }
 constexpr int wave_radix(int rem, int cap) { return rem < cap ? rem : cap; }
+// lanes that share a frame: the whole wave from M = 256 on (float64: 128, measured); below, M / 4 (the butterflies of a radix-4
+// pass), at least 8: a wave then transforms 2 to 8 short frames side by side instead of idling lanes
+constexpr int wave_gl(int M, int elem) { return (M >= 256 || (elem == 8 && M >= 128)) ? 64 : (M / 4 < 8 ? 8 : M / 4); }
 constexpr int wave_slots(int M) { return wpad(M) + 1; }
 // Pass twiddles: the pass that starts at sub-transform length ns (radix R) multiplies input t of butterfly
 // j by W_{ns R}^{k t}, k = j mod ns.  They are laid out per pass as [t - 1][k], so that the lanes of a wave
@@ -54,7 +57,7 @@ constexpr bool wave_inplace(int M, int elem) { return elem == 4 && M / 64 >= 4 &
 constexpr int wave_target(int M, int elem) { return (M <= 256 || wave_inplace(M, elem)) ? 16 : 12; }
 // LDS of a workgroup of wpw waves: W_nfft^k, k < M, for the split; the pass twiddles; the window (M
 // pairs); one or two buffers per wave
-constexpr long wave_lds_of(int M, int elem, int wpw) { return (2L * M + wave_tw_off(M, elem, M) + (wave_inplace(M, elem) ? 1L : 2L) * wave_slots(M) * wpw) * 2 * elem; }
+constexpr long wave_lds_of(int M, int elem, int wpw) { return (2L * M + wave_tw_off(M, elem, M) + (wave_inplace(M, elem) ? 1L : 2L) * wave_slots(M) * wpw * (64 / wave_gl(M, elem))) * 2 * elem; }
 // waves per workgroup (1..8): the smallest count that puts the most waves (up to wave_target) on a CU's
 // 160 KB; 0: the buffers do not fit at all
 constexpr int wave_wpw(int M, int elem)
@@ -94,13 +97,14 @@ template <typename T, int M, int R, int NS>
 __device__ __forceinline__ void wave_pass(const cx<T> *src, cx<T> *dst, const cx<T> *tw, const int lane)
 {
     using C = cx<T>;
+    constexpr int GL = wave_gl(M, (int)sizeof(T));                         // lanes on this frame; lane: index among them
     constexpr int NB = M / R;                              // butterflies
-    constexpr int IT = NB >= 64 ? NB / 64 : 1;
+    constexpr int IT = NB >= GL ? NB / GL : 1;
     constexpr int OFF = wave_tw_off(M, (int)sizeof(T), NS);
 #pragma unroll 1
     for (int i = 0; i < IT; ++i) {                         // rolled: unrolled, the copies' registers add up
-        const int j = lane + 64 * i;
-        if (NB < 64 && lane >= NB) { continue; }
+        const int j = lane + GL * i;
+        if (NB < GL && lane >= NB) { continue; }
         const int k = j & (NS - 1);
         C v[R];
 #pragma unroll
@@ -130,23 +134,24 @@ template <typename T, int M, int R, int NS>
 __device__ __forceinline__ void wave_pass_inplace(cx<T> *buf, const cx<T> *tw, const int lane)
 {
     using C = cx<T>;
+    constexpr int GL = wave_gl(M, (int)sizeof(T));
     constexpr int NB = M / R;
-    constexpr int IT = NB >= 64 ? NB / 64 : 1;
+    constexpr int IT = NB >= GL ? NB / GL : 1;
     constexpr int OFF = wave_tw_off(M, (int)sizeof(T), NS);
-    const bool active = NB >= 64 || lane < NB;
+    const bool active = NB >= GL || lane < NB;
     C v[IT][R];
     if (active) {
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
 #pragma unroll
-            for (int t = 0; t < R; ++t) { v[i][t] = buf[wpad(lane + 64 * i + t * NB)]; }
+            for (int t = 0; t < R; ++t) { v[i][t] = buf[wpad(lane + GL * i + t * NB)]; }
         }
     }
     wave_sync();
     if (active) {
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
-            const int j = lane + 64 * i;
+            const int j = lane + GL * i;
             const int k = j & (NS - 1);
             if (NS > 1) {
 #pragma unroll
@@ -220,9 +225,12 @@ __global__ __launch_bounds__(64 * wave_wpw(NFFT / 2, (int)sizeof(T)), 2) void st
     constexpr int M = NFFT / 2, F = M + 1;
     constexpr int WPW = wave_wpw(M, (int)sizeof(T));
     constexpr int SLOTS = wave_slots(M);
-    constexpr int E = M >= 64 ? M / 64 : 1;                // pairs per lane
+    constexpr int GL = wave_gl(M, (int)sizeof(T)), FPW = 64 / GL;          // lanes per frame, frames per wave
+    constexpr int E = M >= GL ? M / GL : 1;                // pairs per lane
     constexpr int U = E < 8 ? E : 8;                       // pairs per lane and block of loads
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x;
+    const int lane = tid & (GL - 1);                       // index among the lanes of the frame
+    const int grp = (tid & 63) / GL;                       // which of the wave's frames
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int L = d.L;
 
@@ -233,7 +241,7 @@ __global__ __launch_bounds__(64 * wave_wpw(NFFT / 2, (int)sizeof(T)), 2) void st
     C *ptw = twl + M;
     C *wl = ptw + TWN;
     constexpr int NBUF = wave_inplace(M, (int)sizeof(T)) ? 1 : 2;
-    C *buf0 = wl + M + (size_t)wv * NBUF * SLOTS;
+    C *buf0 = wl + M + (size_t)(wv * FPW + grp) * NBUF * SLOTS;
     C *buf1 = buf0 + (NBUF - 1) * SLOTS;
     for (int m = tid; m < M; m += 64 * WPW) {
         twl[m] = cx_make<T>(tw[2 * m], tw[2 * m + 1]);
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(64 * wave_wpw(NFFT / 2, (int)sizeof(T)), 2) void st
     __syncthreads();
 
     const long long total = (long long)d.B * d.W;
-    const long long stride = (long long)gridDim.x * WPW;
+    const long long stride = (long long)gridDim.x * WPW * FPW;
 
     // where a frame lies
     struct Where { const T *xb; long long ss, rdoff, row; bool inside; };
@@ -258,14 +266,14 @@ __global__ __launch_bounds__(64 * wave_wpw(NFFT / 2, (int)sizeof(T)), 2) void st
         q.inside = q.ss >= 0 && q.ss + L <= d.N && q.ss >= q.rdoff;
         return q;
     };
-    // The pairs m0 + 64 u + lane, u < U, of a frame: the loads of a block go out together, one round
+    // The pairs m0 + GL u + lane, u < U, of a frame: the loads of a block go out together, one round
     // trip to memory per block.  Frames across a signal edge: sample by sample.
     auto load_block = [&](const Where &q, const int m0, C (&x)[U]) {
         if (q.inside) {
             const T *src = q.xb + (q.ss - q.rdoff);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int l = 2 * (m0 + 64 * u + lane);
+                const int l = 2 * (m0 + GL * u + lane);
                 x[u] = cx_make<T>(T(0), T(0));
                 if (l + 1 < L) { const T2u v = *reinterpret_cast<const T2u *>(src + l); x[u] = cx_make<T>(v.x, v.y); }
                 else if (l < L) { x[u].x = src[l]; }
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(64 * wave_wpw(NFFT / 2, (int)sizeof(T)), 2) void st
         } else {
 #pragma unroll 1
             for (int u = 0; u < U; ++u) {
-                const int l = 2 * (m0 + 64 * u + lane);
+                const int l = 2 * (m0 + GL * u + lane);
                 const T v0 = (l < L) ? fetch_sample(q.xb, d, q.ss, q.rdoff, l) : T(0);
                 const T v1 = (l + 1 < L) ? fetch_sample(q.xb, d, q.ss, q.rdoff, l + 1) : T(0);
 #pragma unroll
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(64 * wave_wpw(NFFT / 2, (int)sizeof(T)), 2) void st
         }
     };
 
-    long long fi = (long long)blockIdx.x * WPW + wv;
+    long long fi = ((long long)blockIdx.x * WPW + wv) * FPW + grp;
     if (fi >= total) { return; }
     Where cur = locate(fi);
     C xn[U];                                                // first block of the frame to come
@@ -297,12 +305,12 @@ __global__ __launch_bounds__(64 * wave_wpw(NFFT / 2, (int)sizeof(T)), 2) void st
 #pragma unroll
                 for (int u = 0; u < U; ++u) { x[u] = xn[u]; }
             } else {
-                load_block(cur, 64 * U * blk, x);
+                load_block(cur, GL * U * blk, x);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int m = 64 * U * blk + 64 * u + lane;
-                if (M >= 64 || m < M) {
+                const int m = GL * U * blk + GL * u + lane;
+                if (M >= GL || m < M) {
                     const C z = x[u] * wl[m];
                     part += z.x + z.y;
                     buf0[wpad(m)] = z;
@@ -318,10 +326,10 @@ __global__ __launch_bounds__(64 * wave_wpw(NFFT / 2, (int)sizeof(T)), 2) void st
         }
         if (d.mn0) {
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { part += __shfl_xor(part, o); }
+            for (int o = 1; o < GL; o <<= 1) { part += __shfl_xor(part, o); }
             const T mean = part / T(L);
             wave_sync();
-            for (int m = lane; 2 * m < L; m += 64) {
+            for (int m = lane; 2 * m < L; m += GL) {
                 C z = buf0[wpad(m)];
                 z.x -= mean;
                 if (2 * m + 1 < L) { z.y -= mean; }
@@ -335,10 +343,10 @@ __global__ __launch_bounds__(64 * wave_wpw(NFFT / 2, (int)sizeof(T)), 2) void st
         // real-FFT split fused with power: with A = Z_k + conj Z_{M-k}, B = Z_k - conj Z_{M-k},
         // X_k = (A - i W^k B)/2 and X_{M-k} = conj((A + i W^k B)/2)
         T *y = Y + row * (long long)F;
-        constexpr int KI = (M / 2 + 1 + 63) / 64;
+        constexpr int KI = (M / 2 + 1 + GL - 1) / GL;
 #pragma unroll
         for (int i = 0; i < KI; ++i) {
-            const int k = lane + 64 * i;
+            const int k = lane + GL * i;
             if (k <= M / 2) {
                 const int km = (M - k) & (M - 1);
                 const C z = res[wpad(k)], zm = res[wpad(km)];
@@ -366,7 +374,8 @@ static hipError_t launch_wave_inst(T *Y, const T *X, const T *win, const T *tw, 
     if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_wave_kernel<T, NFFT>), lds, grant); e != hipSuccess) { return e; }
     const long long total = (long long)d.B * d.W;
     const long long per_cu = std::max<long long>(1, std::min<long long>(wave_target(M, (int)sizeof(T)) / WPW > 0 ? wave_target(M, (int)sizeof(T)) / WPW : 1, (long long)(160 * 1024 / lds)));   // resident workgroups per CU
-    long long grid = (total + WPW - 1) / WPW;
+    constexpr int FPW = 64 / wave_gl(M, (int)sizeof(T));
+    long long grid = (total + WPW * FPW - 1) / (WPW * FPW);
     grid = std::min(grid, 256 * per_cu);
     hipLaunchKernelGGL((stft_wave_kernel<T, NFFT>), dim3((unsigned)grid), dim3(64 * WPW), lds, s, Y, X, win, tw, d);
     return hipGetLastError();

@@ -314,8 +314,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
             const T mean = sum / T(L);
 #pragma unroll
             for (int n1 = 0; n1 < NR; ++n1) {
-                const int l = 32 * n1 + 2 * j;
-                zz[n1] -= C{(l < L) ? mean : T(0), (l + 1 < L) ? mean : T(0)};
+                if (NR == 16 || n1 == NR - 1) {          // rows that may reach past the window
+                    const int l = 32 * n1 + 2 * j;
+                    zz[n1] -= C{(l < L) ? mean : T(0), (l + 1 < L) ? mean : T(0)};
+                } else {
+                    zz[n1] -= C{mean, mean};
+                }
             }
         }
 #if R512F_ABLATE != 3

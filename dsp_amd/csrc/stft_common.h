@@ -63,8 +63,9 @@ __device__ __forceinline__ double epi_sqrt(double v) { return sqrt(v); }
 __device__ __forceinline__ float epi_log(float v)
 {
     const float l2 = __builtin_amdgcn_logf(v);                       // log2(v)
-    const float r = fmaf(l2, 0.693147182464599609375f, l2 * -1.9046542121259336e-09f);   // ln 2 = hi + lo
-    return (fabsf(l2) == __builtin_inff()) ? l2 : r;                  // log(0) = -inf, log(inf) = inf (inf - inf above)
+    // ln 2 = hi + lo with hi the float BELOW ln 2, so that both parts have the sign of l2 and log(0) = -inf,
+    // log(inf) = inf come out of the same two instructions (no inf - inf)
+    return fmaf(l2, 0.6931471228599548f, l2 * 5.769998878690785e-08f);
 }
 __device__ __forceinline__ double epi_log(double v) { return log(v); }
 // Cube root and power of the same values.  float: from the hardware's log2 and exp2, ~10 instructions

@@ -1,16 +1,18 @@
-// Wavefront-per-frame fused STFT kernels for gfx950: the power-of-two transform lengths that have no
-// kernel of their own (reference c/stft.c:33-162: frame, window, [mean-0], real FFT, power, [sqrt][log]).
+// Fused STFT kernels for gfx950 for the power-of-two transform lengths that have no kernel of their own
+// (reference c/stft.c:33-162: frame, window, [mean-0], real FFT, power, [sqrt][log]).
 //
 // The nfft real samples of a frame are packed as M = nfft/2 complex points z_n = x_2n + i x_2n+1 and
-// transformed by a Stockham autosort FFT: every pass reads R-point butterflies from one LDS buffer,
+// transformed by a Stockham autosort FFT: every pass reads R-point butterflies from an LDS buffer,
 // applies the pass twiddles, transforms them in registers (radix 16, 8, 4 or 2, the packed helpers of
-// fft16.h) and writes them to the other buffer in the order the next pass reads; the result of the last
-// pass is in natural order.  A frame belongs to ONE wavefront, so the passes are separated by wave-level
-// fences only (the one-workgroup-per-frame kernel of generic_kernels.hip pays log2(M) workgroup barriers
-// per frame).  nfft is a template parameter: the radix plan, the loop counts and all LDS offsets are
+// fft16.h) and writes them in the order the next pass reads (to a second buffer, or in place behind a
+// fence); the result of the last pass is in natural order.  A frame belongs to a group of lanes: 8 to 32
+// lanes for the short transforms (a wave then works on 2 to 8 frames side by side), one wavefront in the
+// middle, and a workgroup of 256 threads for the longest.  Up to one wavefront the passes are separated by
+// wave-level fences only (the generic kernel of generic_kernels.hip pays log2(M) workgroup barriers per
+// frame).  nfft is a template parameter: the radix plan, the loop counts and all LDS offsets are
 // compile-time constants.  The real-FFT split is fused with the power step and the epilogue; rows are
-// stored lane-linear in both directions.  The first 512 pairs of the next frame are loaded while the
-// passes of the current one run.
+// stored lane-linear in both directions.  The first pairs of the next frame (8 per lane) are loaded while
+// the passes of the current one run.
 #include "stft_common.h"
 #include "fft16.h"
 
@@ -30,7 +32,12 @@ constexpr int wave_cap(int M, int elem) { return M / 64 < 4 ? 4 : (M / 64 > (ele
 constexpr int wave_radix(int rem, int cap) { return rem < cap ? rem : cap; }
 // lanes that share a frame: the whole wave from M = 256 on (float64: 128, measured); below, M / 4 (the butterflies of a radix-4
 // pass), at least 8: a wave then transforms 2 to 8 short frames side by side instead of idling lanes
-constexpr int wave_gl(int M, int elem) { return (M >= 256 || (elem == 8 && M >= 128)) ? 64 : (M / 4 < 8 ? 8 : M / 4); }
+// The longest transforms (float32 from nfft 4096, float64 from 2048: a wave alone has neither the registers
+// nor the LDS for them) take a whole workgroup of 256 threads per frame, with workgroup barriers between the
+// passes.
+constexpr bool wave_wg(int M, int elem) { return M * elem >= 8192; }
+constexpr int wave_gl(int M, int elem) { return wave_wg(M, elem) ? 256 : ((M >= 256 || (elem == 8 && M >= 128)) ? 64 : (M / 4 < 8 ? 8 : M / 4)); }
+template <int GL> __device__ __forceinline__ void frame_sync() { if constexpr (GL > 64) { __syncthreads(); } else { wave_sync(); } }
 constexpr int wave_slots(int M) { return wpad(M) + 1; }
 // Pass twiddles: the pass that starts at sub-transform length ns (radix R) multiplies input t of butterfly
 // j by W_{ns R}^{k t}, k = j mod ns.  They are laid out per pass as [t - 1][k], so that the lanes of a wave
@@ -50,18 +57,19 @@ constexpr int wave_tw_off(int M, int elem, int ns_target)
 // of two, i.e. twice the waves per CU for the LDS, but no overlap of a pass's reads and writes.  It pays
 // where the LDS limits the waves and the registers allow more: float32 nfft 512 and 1024 (nfft 1024: 0.80 -> 0.70 ms at 16
 // waves per CU; nfft 2048 float32 0.76 -> 0.86 and nfft 1024 float64 1.73 -> 1.99 with it: kept out).
-constexpr bool wave_inplace(int M, int elem) { return elem == 4 && M / 64 >= 4 && M / 64 <= 8; }
+constexpr bool wave_inplace(int M, int elem) { return (elem == 4 && M / 64 >= 4 && M / 64 <= 8) || M * elem >= 8192; }
 // waves per CU worth having: the kernels wait on LDS round trips more than they compute, so as many as the
 // registers allow: 16 for the short transforms and the in-place ones, 12 above (measured, nfft 256: 0.92 ms at 8 waves, 0.59 at
 // 16; nfft 1024 at 129 registers: 1.07 ms at 8, 0.82 at 12, 1.18 at 14 in two workgroups of 7)
 constexpr int wave_target(int M, int elem) { return (M <= 256 || wave_inplace(M, elem)) ? 16 : 12; }
 // LDS of a workgroup of wpw waves: W_nfft^k, k < M, for the split; the pass twiddles; the window (M
 // pairs); one or two buffers per wave
-constexpr long wave_lds_of(int M, int elem, int wpw) { return (2L * M + wave_tw_off(M, elem, M) + (wave_inplace(M, elem) ? 1L : 2L) * wave_slots(M) * wpw * (64 / wave_gl(M, elem))) * 2 * elem; }
+constexpr long wave_lds_of(int M, int elem, int wpw) { return (2L * M + wave_tw_off(M, elem, M) + (wave_inplace(M, elem) ? 1L : 2L) * wave_slots(M) * (wave_wg(M, elem) ? 1 : wpw * (64 / wave_gl(M, elem)))) * 2 * elem + 64; }
 // waves per workgroup (1..8): the smallest count that puts the most waves (up to wave_target) on a CU's
 // 160 KB; 0: the buffers do not fit at all
 constexpr int wave_wpw(int M, int elem)
 {
+    if (wave_wg(M, elem)) { return wave_lds_of(M, elem, 4) <= 160 * 1024 ? 4 : 0; }
     int best = 0, best_waves = 0;
     for (int wpw = 1; wpw <= 8; ++wpw) {
         const long lds = wave_lds_of(M, elem, wpw);
@@ -147,7 +155,7 @@ __device__ __forceinline__ void wave_pass_inplace(cx<T> *buf, const cx<T> *tw, c
             for (int t = 0; t < R; ++t) { v[i][t] = buf[wpad(lane + GL * i + t * NB)]; }
         }
     }
-    wave_sync();
+    frame_sync<GL>();
     if (active) {
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
@@ -204,11 +212,11 @@ __device__ __forceinline__ cx<T> *wave_passes(cx<T> *src, cx<T> *dst, const cx<T
         constexpr int R = wave_radix(M / NS, wave_cap(M, (int)sizeof(T)));
         if constexpr (wave_inplace(M, (int)sizeof(T))) {
             wave_pass_inplace<T, M, R, NS>(src, tw, lane);
-            wave_sync();
+            frame_sync<wave_gl(M, (int)sizeof(T))>();
             return wave_passes<T, M, NS * R>(src, dst, tw, lane);
         } else {
             wave_pass<T, M, R, NS>(src, dst, tw, lane);
-            wave_sync();
+            frame_sync<wave_gl(M, (int)sizeof(T))>();
             return wave_passes<T, M, NS * R>(dst, src, tw, lane);
         }
     }
@@ -225,12 +233,14 @@ __global__ __launch_bounds__(64 * wave_wpw(NFFT / 2, (int)sizeof(T)), 2) void st
     constexpr int M = NFFT / 2, F = M + 1;
     constexpr int WPW = wave_wpw(M, (int)sizeof(T));
     constexpr int SLOTS = wave_slots(M);
-    constexpr int GL = wave_gl(M, (int)sizeof(T)), FPW = 64 / GL;          // lanes per frame, frames per wave
+    constexpr int GL = wave_gl(M, (int)sizeof(T));         // lanes per frame
+    constexpr bool WG = GL > 64;                           // the workgroup shares one frame
+    constexpr int FPW = WG ? 1 : 64 / GL;                  // frames per wave
     constexpr int E = M >= GL ? M / GL : 1;                // pairs per lane
     constexpr int U = E < 8 ? E : 8;                       // pairs per lane and block of loads
     const int tid = threadIdx.x;
     const int lane = tid & (GL - 1);                       // index among the lanes of the frame
-    const int grp = (tid & 63) / GL;                       // which of the wave's frames
+    const int grp = WG ? 0 : (tid & 63) / GL;              // which of the wave's frames
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int L = d.L;
 
@@ -241,8 +251,9 @@ __global__ __launch_bounds__(64 * wave_wpw(NFFT / 2, (int)sizeof(T)), 2) void st
     C *ptw = twl + M;
     C *wl = ptw + TWN;
     constexpr int NBUF = wave_inplace(M, (int)sizeof(T)) ? 1 : 2;
-    C *buf0 = wl + M + (size_t)(wv * FPW + grp) * NBUF * SLOTS;
+    C *buf0 = wl + M + (WG ? 0 : (size_t)(wv * FPW + grp) * NBUF * SLOTS);
     C *buf1 = buf0 + (NBUF - 1) * SLOTS;
+    T *red = reinterpret_cast<T *>(wl + M + (size_t)(WG ? 1 : WPW * FPW) * NBUF * SLOTS);   // WG: 4 partial sums
     for (int m = tid; m < M; m += 64 * WPW) {
         twl[m] = cx_make<T>(tw[2 * m], tw[2 * m + 1]);
         wl[m] = cx_make<T>(2 * m < L ? win[2 * m] : T(0), 2 * m + 1 < L ? win[2 * m + 1] : T(0));
@@ -251,7 +262,7 @@ __global__ __launch_bounds__(64 * wave_wpw(NFFT / 2, (int)sizeof(T)), 2) void st
     __syncthreads();
 
     const long long total = (long long)d.B * d.W;
-    const long long stride = (long long)gridDim.x * WPW * FPW;
+    const long long stride = WG ? (long long)gridDim.x : (long long)gridDim.x * WPW * FPW;
 
     // where a frame lies
     struct Where { const T *xb; long long ss, rdoff, row; bool inside; };
@@ -290,7 +301,7 @@ __global__ __launch_bounds__(64 * wave_wpw(NFFT / 2, (int)sizeof(T)), 2) void st
         }
     };
 
-    long long fi = ((long long)blockIdx.x * WPW + wv) * FPW + grp;
+    long long fi = WG ? (long long)blockIdx.x : ((long long)blockIdx.x * WPW + wv) * FPW + grp;
     if (fi >= total) { return; }
     Where cur = locate(fi);
     C xn[U];                                                // first block of the frame to come
@@ -326,9 +337,14 @@ __global__ __launch_bounds__(64 * wave_wpw(NFFT / 2, (int)sizeof(T)), 2) void st
         }
         if (d.mn0) {
 #pragma unroll
-            for (int o = 1; o < GL; o <<= 1) { part += __shfl_xor(part, o); }
+            for (int o = 1; o < (WG ? 64 : GL); o <<= 1) { part += __shfl_xor(part, o); }
+            if constexpr (WG) {
+                if ((tid & 63) == 0) { red[wv] = part; }
+                __syncthreads();
+                part = red[0] + red[1] + red[2] + red[3];
+            }
             const T mean = part / T(L);
-            wave_sync();
+            frame_sync<GL>();
             for (int m = lane; 2 * m < L; m += GL) {
                 C z = buf0[wpad(m)];
                 z.x -= mean;
@@ -336,7 +352,7 @@ __global__ __launch_bounds__(64 * wave_wpw(NFFT / 2, (int)sizeof(T)), 2) void st
                 buf0[wpad(m)] = z;
             }
         }
-        wave_sync();
+        frame_sync<GL>();
 
         const C *res = wave_passes<T, M, 1>(buf0, buf1, ptw, lane);
 
@@ -360,7 +376,7 @@ __global__ __launch_bounds__(64 * wave_wpw(NFFT / 2, (int)sizeof(T)), 2) void st
             }
         }
         if (!more) { break; }
-        wave_sync();
+        frame_sync<GL>();
     }
 }
 
@@ -374,8 +390,9 @@ static hipError_t launch_wave_inst(T *Y, const T *X, const T *win, const T *tw, 
     if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_wave_kernel<T, NFFT>), lds, grant); e != hipSuccess) { return e; }
     const long long total = (long long)d.B * d.W;
     const long long per_cu = std::max<long long>(1, std::min<long long>(wave_target(M, (int)sizeof(T)) / WPW > 0 ? wave_target(M, (int)sizeof(T)) / WPW : 1, (long long)(160 * 1024 / lds)));   // resident workgroups per CU
-    constexpr int FPW = 64 / wave_gl(M, (int)sizeof(T));
-    long long grid = (total + WPW * FPW - 1) / (WPW * FPW);
+    constexpr bool WG = wave_wg(M, (int)sizeof(T));
+    constexpr int FPW = WG ? 1 : 64 / wave_gl(M, (int)sizeof(T));
+    long long grid = WG ? total : (total + WPW * FPW - 1) / (WPW * FPW);
     grid = std::min(grid, 256 * per_cu);
     hipLaunchKernelGGL((stft_wave_kernel<T, NFFT>), dim3((unsigned)grid), dim3(64 * WPW), lds, s, Y, X, win, tw, d);
     return hipGetLastError();
@@ -386,7 +403,7 @@ bool wave_fft_supported(const FrameDesc &d)
 {
     const int n = d.nfft;
     if (n < 16 || (n & (n - 1)) != 0 || d.L < 1 || d.L > n) { return false; }
-    return n <= (sizeof(T) == 4 ? 4096 : 1024);          // float64 2048 needs more registers than there are: no gain over the generic kernel
+    return n <= (sizeof(T) == 4 ? 8192 : 4096);
 }
 
 template <typename T>
@@ -401,8 +418,9 @@ hipError_t launch_stft_wave(T *Y, const T *X, const T *win, const T *tw, const F
     case 512: return launch_wave_inst<T, 512>(Y, X, win, tw, d, s);
     case 1024: return launch_wave_inst<T, 1024>(Y, X, win, tw, d, s);
     case 2048: return launch_wave_inst<T, 2048>(Y, X, win, tw, d, s);
-    case 4096:
-        if constexpr (sizeof(T) == 4) { return launch_wave_inst<T, 4096>(Y, X, win, tw, d, s); }
+    case 4096: return launch_wave_inst<T, 4096>(Y, X, win, tw, d, s);
+    case 8192:
+        if constexpr (sizeof(T) == 4) { return launch_wave_inst<T, 8192>(Y, X, win, tw, d, s); }
         return hipErrorInvalidValue;
     default: return hipErrorInvalidValue;
     }

@@ -15,7 +15,7 @@ def run(nfft, L, hop, B, N, dt):
     W = y.shape[1]; es = x.element_size()
     byts = B * W * (hop + nfft // 2 + 1) * es
     return ms, byts / ms / 8e9 * 100, B * W / ms / 1e3
-for nfft in (16, 32, 64, 128, 256, 1024, 2048, 4096):
+for nfft in (16, 32, 64, 128, 256, 1024, 2048, 4096, 8192):
     L, hop = nfft, nfft // 4
     N = 1 << 26
     B = 8

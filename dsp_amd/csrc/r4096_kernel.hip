@@ -1,24 +1,30 @@
 // Register-resident 4096-point fused STFT kernel for gfx950 (float32): framing + window +
-// [mean removal] + real FFT + power + [sqrt][log], one wavefront per frame.
+// [mean removal] + real FFT + power + [sqrt][log], one wavefront per frame, eight waves per workgroup
+// sharing the halved window in LDS, one workgroup per CU (151.5 KB of LDS: a 16.9 KB tile per wave).
 //
 // The 4096 real samples of a frame are packed as 2048 complex points z_n = x_2n + i x_2n+1 and
 // transformed as 32 x 64, every complex value one (re, im) register pair so that the butterflies
 // run on the packed two-component float instructions:
-//   pass 1  lane n2 (0..63) loads its 32 points z[64 n1 + n2] straight from global memory (for a
-//           fixed n1 the wave reads 512 contiguous bytes), multiplies by the window (LDS table),
-//           runs a 32-point FFT over n1 in registers and multiplies by W2048^(n2 k1);
-//   radix-2 the first (decimation-in-frequency) stage of the 64-point transforms over n2 pairs lane
-//           n2 with lane n2 + 32: one v_permlane32_swap per register hands rows k1 < 16 to the lower
-//           half-wave and rows k1 >= 16 to the upper one, each lane then holding both inputs of its
-//           butterfly; u = x + y feeds the even outputs, v = (x - y) W64^n2 the odd ones;
+//   loads   half-wave u takes the rows n1 = 2 i + u, lane l of it the complex columns 2 l and 2 l + 1:
+//           sixteen 16-byte loads per lane, each wave load 1 KiB contiguous;
+//   pass 1  window (LDS, 16-byte reads), two 16-point FFTs over the half-wave's rows, then one
+//           v_permlane32_swap per register trades a column between the half-waves: every lane holds the
+//           even-row and odd-row transforms of ONE column n2 = 2 l + u and finishes the 32-point FFT in
+//           registers; twiddle W2048^(n2 k1) as two per-lane factors (k1 = 4 q + b);
+//   radix-2 the first (decimation-in-frequency) stage of the 64-point transforms over n2 pairs column
+//           n2 with n2 + 32, 16 lanes apart: one v_permlane16_swap of rows k1 and k1 + 16 gives every
+//           lane both inputs of its butterfly; u = x + y feeds the even outputs, v = (x - y) W64^n2
+//           the odd ones;
 //   exchange through LDS: 64 rows (k1, parity) of 32 values, pitch 33 (conflict-free both ways);
 //   pass 2  lane (k1, parity) runs one 32-point FFT and holds Z[k1 + 32 parity + 64 k'];
-//   split   Z goes to LDS once, each lane reads bins k and 2048-k, and the real-FFT split is fused
-//           with the power step; rows are stored as whole 256-byte wave stores.
-// The next frame's samples are requested as soon as the registers are free (under the split and
-// the stores).  Frames are dealt round-robin inside 8 contiguous ranges (one per group of
-// workgroups that share an XCD), so the 3/4 of a frame that overlaps its neighbours is served by
-// that XCD's L2 and every sample is fetched from HBM once.
+//   split   Z goes to LDS once, each lane reads bins 4 lane + c + 256 m and 2048 minus those, and the
+//           real-FFT split is fused with the power step; 16-byte stores of 4 consecutive bins in both
+//           directions.
+// Two forms of the frame loop (template parameter RUN): with a full window and a hop of 1024 a wave
+// works through runs of 16 consecutive frames, loads every sample once and keeps the frame rotated in
+// its registers; otherwise frames are dealt round-robin inside 8 contiguous ranges (one per group of
+// workgroups that share an XCD) and the waves of a workgroup stay in step, so that the 3/4 of a frame
+// that overlaps its neighbours is served by that XCD's L2.  Both are described where the loop starts.
 #include <mutex>
 #include <type_traits>
 #include "stft_common.h"

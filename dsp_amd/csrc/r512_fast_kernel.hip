@@ -6,7 +6,10 @@
 //     current 4 frames are transformed, and is committed to LDS at the top of the next step, so the
 //     HBM latency is off the critical path; every input sample is fetched once per run of frames;
 //   * the staged span and the 16 x 16 exchange tile share one LDS region (8.7 KB per wave in
-//     float), which lets four workgroups share a CU;
+//     float); two workgroups of four waves run on a CU (the registers, not the LDS, set that), swap
+//     issue priority every step and keep their waves in step with a barrier every fourth step;
+//   * rows leave as 16-byte non-temporal stores of the step's 4 x 257 values, staged through LDS in
+//     the order they have in the output;
 //   * the compile-time shape (rows of the window that hold data, mean removal, sqrt/log epilogue)
 //     removes the per-element selects and branches of the general kernel.
 #include "stft_common.h"
@@ -29,7 +32,7 @@ struct R512FastArgs {
     int steps;            // B * sps
 };
 
-constexpr int R512F_WAVE_ELEMS = 4 * R512_EXF * 2;   // T elements of LDS per wave (>= 1024 staged samples)
+constexpr int R512F_WAVE_ELEMS = 4 * R512_EXF * 2;   // T elements of LDS per wave (>= 1280 staged samples)
 
 // value of lane (16 - i) % 16 of the same 16-lane row (row_mirror, then row_ror:1)
 __device__ __forceinline__ int dpp_partner16_i(int v)

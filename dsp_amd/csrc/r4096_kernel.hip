@@ -21,7 +21,7 @@
 //           real-FFT split is fused with the power step; 16-byte stores of 4 consecutive bins in both
 //           directions.
 // Two forms of the frame loop (template parameter RUN): with a full window and a hop of 1024 a wave
-// works through runs of 16 consecutive frames, loads every sample once and keeps the frame rotated in
+// works through runs of 32 consecutive frames, loads every sample once and keeps the frame rotated in
 // its registers; otherwise frames are dealt round-robin inside 8 contiguous ranges (one per group of
 // workgroups that share an XCD) and the waves of a workgroup stay in step, so that the 3/4 of a frame
 // that overlaps its neighbours is served by that XCD's L2.  Both are described where the loop starts.
@@ -78,7 +78,7 @@ typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));   // 16-
 #define R4096_ALT_PRIO 0
 #endif
 #ifndef R4096_RUN
-#define R4096_RUN 16            // frames per run of the run form
+#define R4096_RUN 32            // frames per run of the run form
 #endif
 #ifndef R4096_STAMPS
 #define R4096_STAMPS 0          // diagnostic builds: 1 = per-phase s_memtime sums into g_r4096_stamps

@@ -192,14 +192,14 @@ def test_both_4096_families_agree_with_oracle(O, D):
 
 
 def test_4096_run_form_agrees_with_oracle(O, D, monkeypatch):
-    """Full window with hop 1024: large inputs are transformed in runs of 16 consecutive frames per wave
+    """Full window with hop 1024: large inputs are transformed in runs of 32 consecutive frames per wave
     (each sample loaded once, the frame held rotated in registers).  Forced here at small sizes: runs
-    that cross either edge of the signal, a last run shorter than 16, a signal shorter than one run,
+    that cross either edge of the signal, a last run shorter than 32, a signal shorter than one run,
     several signals, every flag; then the frame form on the same input."""
     import torch
     dt = np.float32
     win = D.blackmanharris(4096, dt)
-    for (N, flags) in [(40000, (0, 0, 0)), (16 * 1024 * 3 + 700, (1, 0, 0)), (100000, (0, 1, 1)), (5000, (1, 1, 0)), (4096 + 1024 * 31, (0, 0, 1))]:
+    for (N, flags) in [(40000, (0, 0, 0)), (32 * 1024 * 2 + 700, (1, 0, 0)), (100000, (0, 1, 1)), (5000, (1, 1, 0)), (4096 + 1024 * 63, (0, 0, 1))]:
         x = signal(N, N, dt) + dt(0.2)
         for snip in (0, 1):
             rc, Yref = O.stft(x.astype(np.float64), win.astype(np.float64), 1024, 4096, snip, *flags, exact=False)

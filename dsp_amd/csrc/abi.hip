@@ -4,6 +4,7 @@
 #include "stft_common.h"
 #include "../../include/dsp_stft.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cfloat>
 #include <climits>
@@ -210,6 +211,13 @@ int flt_desc(const char *fn, int dev, FrameDesc &d, size_t B, size_t N, size_t l
     memcpy(k, &c0, sizeof(T)); k += sizeof(T);
     memcpy(k, &stp, sizeof(T)); k += sizeof(T);
     k[0] = (unsigned char)sizeof(T); k[1] = (unsigned char)(as_reference != 0);
+    long long reach = (shift == 0) ? 0 : -1;
+    for (size_t w = 0; reach >= 0 && w + 1 < W; ++w) {
+        if (tbl[2 * (w + 1)] < tbl[2 * w]) { reach = -1; break; }
+        const size_t w3 = (w + 3 < W) ? w + 3 : W - 1;
+        reach = std::max(reach, (long long)tbl[2 * w3] - tbl[2 * w]);
+    }
+    d.tbl_reach = (reach >= 0 && reach <= 768) ? (int)reach : -1;
     return get_table(fn, dev, key, tbl, d.tbl);
 }
 

@@ -1,6 +1,7 @@
 // Fast path of the 512-point fused STFT kernel for gfx950: integer hop with 3*hop + 512 <= 1280 (hop <= 256),
 // frames addressed as start = ss0 + w*hop (the stft framing, and the stft_flt framing when
-// its hop is integral).  Same arithmetic as the basic kernel in r512_kernel.hip; what differs is the
+// its hop is integral), or (TBL) frames whose starts come from a table, never decrease and lie at most 768
+// samples apart for frames w and w + 3 (the stft_flt framing with a non-integral hop).  Same arithmetic as the basic kernel in r512_kernel.hip; what differs is the
 // schedule around it:
 //   * the span of the next 4 frames is fetched from HBM into registers (16-byte loads) while the
 //     current 4 frames are transformed, and is committed to LDS at the top of the next step, so the
@@ -23,13 +24,14 @@ struct R512FastArgs {
     int N;                // samples per signal
     int L;                // window length (NR rows of 32 hold data)
     int W;                // frames per signal
-    int stp;              // hop
+    int stp;              // hop (table form: the largest distance between the starts of frames w and w + 3)
     int ss0;              // start of frame 0
     int rd_shift;         // edge == 1: samples are read at n - rd_shift
     int edge;             // 0 reflect, 1 zero
     Epilogue epi;
     int sps;              // steps (groups of 4 consecutive frames) per signal
     int steps;            // B * sps
+    const int *tbl;       // table form: start of frame w at tbl[2 w] (frames need not be equally spaced)
 };
 
 constexpr int R512F_WAVE_ELEMS = 4 * R512_EXF * 2;   // T elements of LDS per wave (>= 1280 staged samples)
@@ -115,7 +117,7 @@ __device__ unsigned long long g_r512f_stamps[8192 * 8];
 #define R512F_MINWAVES_F32 2
 #endif
 
-template <typename T, int NR, bool MN0, bool EPI, bool WIDE>
+template <typename T, int NR, bool MN0, bool EPI, bool WIDE, bool TBL>
 __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) void stft_r512_fast_kernel(T *__restrict__ Y, const T *__restrict__ X,
                                                               const T *__restrict__ win, const T *__restrict__ tw,
                                                               const R512FastArgs a)
@@ -171,14 +173,18 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
         for (int l = tid; l < 512; l += 256) { wtab[l] = (l < L) ? T(0.5) * win[l] : T(0); }
     }
     if (!WINREG || !TWREG) { __syncthreads(); }
-    const int need = 3 * a.stp + 512;
-    const int nvec = (3 * a.stp + 32 * NR + VEC - 1) / VEC;   // 16-byte vectors of a span that pass 1 reads
-    const T *xrow = xs + f * a.stp + 2 * j;
+    static_assert(!TBL || (WIDE && NR == 16), "the table form uses the wide, 16-row instantiation");
+    const int reach = TBL ? a.stp : 3 * a.stp;               // start of the step's last frame relative to its first
+    const int need = reach + 512;
+    const int nvec = (reach + 32 * NR + VEC - 1) / VEC;      // 16-byte vectors of a span that pass 1 reads
+    const T *xrow = xs + f * a.stp + 2 * j;                  // (table form: set per step)
+    // table form: lane i holds the start of frame w + (i & 3) of a step (clamped to the last frame)
+    auto tbl_fetch = [&](const int w_) { return a.tbl[2 * min(w_ + (lane & 3), a.W - 1)]; };
+    auto tbl_xrow = [&](const int tv) { return xs + (__shfl(tv, f) - __builtin_amdgcn_readfirstlane(tv)) + 2 * j; };
 
     // ---- fetch of one span (frames w..w+3 of the signal at xb) into registers ----
     TV pre[NV];
-    auto load_span = [&](const T *xb, const int w) {
-        const int s0 = a.ss0 + w * a.stp;
+    auto load_span = [&](const T *xb, const int s0) {
         const T *src = xb + (s0 - (a.edge ? a.rd_shift : 0));
         const bool inside = s0 >= 0 && s0 + SPAN <= a.N && (a.edge == 0 || s0 >= a.rd_shift);
         if (inside && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
@@ -253,13 +259,22 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory");
 #endif
-    // prologue: first span to LDS, second span in flight
-    load_span(xb, w);
+    // prologue: first span to LDS, second span in flight (table form: the starts of its frames in
+    // flight; its span is fetched in the middle of the step, when they have arrived)
+    int tvn = 0;
+    if constexpr (TBL) {
+        const int tv = tbl_fetch(w);
+        xrow = tbl_xrow(tv);
+        load_span(xb, __builtin_amdgcn_readfirstlane(tv));
+    } else {
+        load_span(xb, a.ss0 + w * a.stp);
+    }
 #pragma unroll
     for (int q = 0; q < NV; ++q) { reinterpret_cast<TV *>(xs)[q * 64 + lane] = pre[q]; }
     wave_sync();
     advance();
-    if (more) { load_span(nxb, nw); }
+    if constexpr (TBL) { if (more) { tvn = tbl_fetch(nw); } }
+    else { if (more) { load_span(nxb, nw * a.stp + a.ss0); } }
 
     // Steady state per step: transform the staged span and store its rows while the next span is in
     // flight; then commit that span to LDS and issue the fetch of the one after.  The stores of a
@@ -328,6 +343,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
 #if R512F_ABLATE != 3
         dft16c<T, NR>(zz);
 #endif
+        const T *nxrow = xrow;
+        if constexpr (TBL) {
+            if (more) { nxrow = tbl_xrow(tvn); load_span(nxb, __builtin_amdgcn_readfirstlane(tvn)); }
+        }
         R512F_STAMP(0);
         wave_sync();                                       // all lanes have read the span: the tile may overwrite it
 #if R512F_ABLATE != 4
@@ -465,7 +484,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
         R512F_STAMP(5);
         sid = nsid; w = nw; xb = nxb; yb = nyb;
         advance();
-        if (more) { load_span(nxb, nw); }
+        if constexpr (TBL) { xrow = nxrow; if (more) { tvn = tbl_fetch(nw); } }
+        else { if (more) { load_span(nxb, nw * a.stp + a.ss0); } }
         R512F_STAMP(6);
     }
 #if R512F_STAMPS
@@ -482,26 +502,28 @@ extern "C" int dsp_debug_read_stamps(unsigned long long *dst, size_t n)
 }
 #endif
 
-// Conditions of the fast path: frames at ss0 + w*hop with 3*hop + 512 <= 1280, and every
-// index of one signal's input and output fits 31 bits.
+// Conditions of the fast path: frames at ss0 + w*hop with 3*hop + 512 <= 1280, or a table of frame starts
+// that never decrease, are read where they start and put frames w and w + 3 at most 768 samples apart;
+// and every index of one signal's input and output fits 31 bits.
 bool r512_fast_supported(const FrameDesc &d)
 {
-    return d.tbl == nullptr && d.nfft == 512 && d.L >= 1 && d.L <= 512 && 3ll * d.stp + 512 <= 1280 &&
+    const bool placed = d.tbl ? (d.tbl_reach >= 0 && d.tbl_reach + 512 <= 1280) : (3ll * d.stp + 512 <= 1280);
+    return placed && d.nfft == 512 && d.L >= 1 && d.L <= 512 &&
            d.N < (1ll << 31) - 4096 && (long long)d.W * 257 < (1ll << 30) && (long long)d.B * ((d.W + 3) / 4) < (1ll << 30) && d.ss0 > -(1ll << 30) && d.ss0 < (1ll << 30) &&
            d.rd_shift >= 0 && d.rd_shift < (1ll << 30);
 }
 
-template <typename T, int NR, bool MN0, bool EPI, bool WIDE>
+template <typename T, int NR, bool MN0, bool EPI, bool WIDE, bool TBL = false>
 static hipError_t launch_fast_inst(T *Y, const T *X, const T *win, const T *tw, const R512FastArgs &a, hipStream_t s)
 {
     const size_t lds = (4 * (size_t)R512F_WAVE_ELEMS + 512 + 512) * sizeof(T);
     static LdsGrant grant;
-    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r512_fast_kernel<T, NR, MN0, EPI, WIDE>), lds, grant); e != hipSuccess) { return e; }
+    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r512_fast_kernel<T, NR, MN0, EPI, WIDE, TBL>), lds, grant); e != hipSuccess) { return e; }
     static const int wgs_per_cu = [] { const char *e = getenv("DSP_R512F_WGS_PER_CU"); return e ? atoi(e) : 2; }();
     long long grid = ((long long)a.steps + 3) / 4;
     if (grid > 256ll * wgs_per_cu) { grid = 256ll * wgs_per_cu; }
     grid = (grid + 7) & ~7ll;                           // whole groups of 8 workgroups (one per XCD)
-    hipLaunchKernelGGL((stft_r512_fast_kernel<T, NR, MN0, EPI, WIDE>), dim3((unsigned)grid), dim3(256), lds, s, Y, X, win, tw, a);
+    hipLaunchKernelGGL((stft_r512_fast_kernel<T, NR, MN0, EPI, WIDE, TBL>), dim3((unsigned)grid), dim3(256), lds, s, Y, X, win, tw, a);
     return hipGetLastError();
 }
 
@@ -513,11 +535,18 @@ hipError_t launch_stft_r512_fast(T *Y, const T *X, const T *win, const T *tw, co
     a.rd_shift = (int)d.rd_shift; a.edge = d.edge; a.epi = d.epi;
     a.sps = (d.W + 3) / 4;
     a.steps = d.B * a.sps;
+    a.tbl = d.tbl;
+    if (d.tbl) { a.stp = d.tbl_reach; a.ss0 = 0; a.rd_shift = 0; }
     const bool epi = d.epi.any();
     const bool wide = 3 * d.stp + 512 > 1024 || (d.stp & 1);   // spans of more than 1024 samples (20 staged elements per lane), odd hops
     const bool nr13 = d.L > 384 && d.L <= 416 && !wide;
 #define DSP_R512F(NR_, MN0_, EPI_) launch_fast_inst<T, NR_, MN0_, EPI_, false>(Y, X, win, tw, a, s)
 #define DSP_R512W(MN0_, EPI_) launch_fast_inst<T, 16, MN0_, EPI_, true>(Y, X, win, tw, a, s)
+#define DSP_R512T(MN0_, EPI_) launch_fast_inst<T, 16, MN0_, EPI_, true, true>(Y, X, win, tw, a, s)
+    if (d.tbl) {
+        if (d.mn0) { return epi ? DSP_R512T(true, true) : DSP_R512T(true, false); }
+        return epi ? DSP_R512T(false, true) : DSP_R512T(false, false);
+    }
     if (wide) {
         if (d.mn0) { return epi ? DSP_R512W(true, true) : DSP_R512W(true, false); }
         return epi ? DSP_R512W(false, true) : DSP_R512W(false, false);
@@ -530,6 +559,7 @@ hipError_t launch_stft_r512_fast(T *Y, const T *X, const T *win, const T *tw, co
     return epi ? DSP_R512F(16, false, true) : DSP_R512F(16, false, false);
 #undef DSP_R512F
 #undef DSP_R512W
+#undef DSP_R512T
 }
 
 template hipError_t launch_stft_r512_fast<float>(float *, const float *, const float *, const float *, const FrameDesc &, hipStream_t);

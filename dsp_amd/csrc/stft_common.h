@@ -27,6 +27,8 @@ struct FrameDesc {
     long long ss0;       // uniform mode: start sample of frame 0
     long long rd_shift;  // uniform mode, edge == 1: ss_w - rd_w (the same for every frame)
     const int *tbl;      // table mode: 2 ints per frame
+    int tbl_reach;       // table mode: max over w of tbl[2(w+3)] - tbl[2w] when the starts never decrease and
+                         // every frame is read where it starts (tbl[2w+1] == tbl[2w]); -1 otherwise
     int L;               // window length
     int nfft;            // transform length
     int W;               // frames per signal

@@ -280,6 +280,30 @@ def test_stft_flt_other_sizes(O, D, dt):
             D.set_flt_mode(False)
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_stft_flt_start_tables_512_batched(O, D, dt):
+    """nfft 512 with non-integral hops on a batch: frame starts that are not equally spaced go through the
+    span-staging kernel while frames w and w + 3 start at most 768 samples apart (hops up to about 255.6), and
+    through the general one beyond; frame counts that are no multiple of 4, frames off both ends, every flag."""
+    import torch
+    B, N = 5, 40000
+    xh = np.stack([signal(40 + b, N, dt) for b in range(B)])
+    x = torch.from_numpy(xh).cuda()
+    for (L, c0, stp, W, flags) in [(400, 200.0, 160.5, 246, (0, 0, 0)), (400, -333.0, 160.5, 251, (1, 0, 0)), (512, 256.0, 255.6, 153, (0, 1, 1)),
+                                   (512, 100.0, 256.4, 155, (0, 0, 0)), (300, 39000.0, 77.77, 41, (1, 1, 0)), (400, 7.0, 1.3, 1021, (0, 0, 1))]:
+        win = D.povey(L, dt)
+        for intended in (False, True):
+            D.set_flt_mode(intended)
+            try:
+                Y = D.stft_flt_dev(x, torch.from_numpy(win).cuda(), W, c0, stp, *[bool(f) for f in flags]).cpu().numpy()
+            finally:
+                D.set_flt_mode(False)
+            for b in range(B):
+                rc, Yref = O.stft_flt(xh[b], win, W, c0, stp, 512, *flags, intended=intended)
+                assert rc == 0
+                check_spec(O, Y[b], Yref, flags[1], flags[2])
+
+
 @pytest.mark.parametrize("tag", ["s", "d"])
 def test_stft_flt_intended_against_reference_fixtures(O, D, tag):
     g = load_golden(f"ref_flt_{tag}.npz")

@@ -217,7 +217,7 @@ int flt_desc(const char *fn, int dev, FrameDesc &d, size_t B, size_t N, size_t l
         const size_t w3 = (w + 3 < W) ? w + 3 : W - 1;
         reach = std::max(reach, (long long)tbl[2 * w3] - tbl[2 * w]);
     }
-    d.tbl_reach = (reach >= 0 && reach <= 768) ? (int)reach : -1;
+    d.tbl_reach = (reach >= 0 && reach <= 1536) ? (int)reach : -1;
     return get_table(fn, dev, key, tbl, d.tbl);
 }
 

@@ -1,6 +1,6 @@
-// Fast path of the 512-point fused STFT kernel for gfx950: integer hop with 3*hop + 512 <= 1280 (hop <= 256),
+// Fast path of the 512-point fused STFT kernel for gfx950: integer hop with 3*hop + 512 <= 2048 (hop <= 512),
 // frames addressed as start = ss0 + w*hop (the stft framing, and the stft_flt framing when
-// its hop is integral), or (TBL) frames whose starts come from a table, never decrease and lie at most 768
+// its hop is integral), or (TBL) frames whose starts come from a table, never decrease and lie at most 1536
 // samples apart for frames w and w + 3 (the stft_flt framing with a non-integral hop).  Same arithmetic as the basic kernel in r512_kernel.hip; what differs is the
 // schedule around it:
 //   * the span of the next 4 frames is fetched from HBM into registers (16-byte loads) while the
@@ -117,15 +117,17 @@ __device__ unsigned long long g_r512f_stamps[8192 * 8];
 #define R512F_MINWAVES_F32 2
 #endif
 
-template <typename T, int NR, bool MN0, bool EPI, bool WIDE, bool TBL>
+template <typename T, int NR, bool MN0, bool EPI, int WIDE, bool TBL>
 __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) void stft_r512_fast_kernel(T *__restrict__ Y, const T *__restrict__ X,
                                                               const T *__restrict__ win, const T *__restrict__ tw,
                                                               const R512FastArgs a)
 {
     using T2 = typename vec2<T>::type;
     using TV = typename vec16<T>::type;
-    // staged elements per lane: 16 (spans of up to 1024 samples: hop <= 170), WIDE: 20 (1280: hop <= 256)
-    constexpr int VEC = vec16<T>::n, SPAN = WIDE ? 1280 : 1024, NV = SPAN / 64 / VEC;
+    // staged elements per lane: 16 (spans of up to 1024 samples: hop <= 170), WIDE 1: 20 (1280: hop <= 256),
+    // WIDE 2: 32 (2048: hop <= 512)
+    constexpr int VEC = vec16<T>::n, SPAN = WIDE == 2 ? 2048 : WIDE ? 1280 : 1024, NV = SPAN / 64 / VEC;
+    static_assert(SPAN <= R512F_WAVE_ELEMS, "the staged span lives in the wave's exchange region");
     constexpr bool WINREG = (sizeof(T) == 4) && !R512F_WIN_LDS;
     constexpr bool TWREG = !R512F_TW_LDS && !(R512F_TW_LDS_F64 && sizeof(T) == 8);
     constexpr int M = 256, F = 257;
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
         for (int l = tid; l < 512; l += 256) { wtab[l] = (l < L) ? T(0.5) * win[l] : T(0); }
     }
     if (!WINREG || !TWREG) { __syncthreads(); }
-    static_assert(!TBL || (WIDE && NR == 16), "the table form uses the wide, 16-row instantiation");
+    static_assert(!TBL || (WIDE >= 1 && NR == 16), "the table form uses the wide, 16-row instantiations");
     const int reach = TBL ? a.stp : 3 * a.stp;               // start of the step's last frame relative to its first
     const int need = reach + 512;
     const int nvec = (reach + 32 * NR + VEC - 1) / VEC;      // 16-byte vectors of a span that pass 1 reads
@@ -502,18 +504,18 @@ extern "C" int dsp_debug_read_stamps(unsigned long long *dst, size_t n)
 }
 #endif
 
-// Conditions of the fast path: frames at ss0 + w*hop with 3*hop + 512 <= 1280, or a table of frame starts
-// that never decrease, are read where they start and put frames w and w + 3 at most 768 samples apart;
+// Conditions of the fast path: frames at ss0 + w*hop with 3*hop + 512 <= 2048, or a table of frame starts
+// that never decrease, are read where they start and put frames w and w + 3 at most 1536 samples apart;
 // and every index of one signal's input and output fits 31 bits.
 bool r512_fast_supported(const FrameDesc &d)
 {
-    const bool placed = d.tbl ? (d.tbl_reach >= 0 && d.tbl_reach + 512 <= 1280) : (3ll * d.stp + 512 <= 1280);
+    const bool placed = d.tbl ? (d.tbl_reach >= 0 && d.tbl_reach + 512 <= 2048) : (3ll * d.stp + 512 <= 2048);
     return placed && d.nfft == 512 && d.L >= 1 && d.L <= 512 &&
            d.N < (1ll << 31) - 4096 && (long long)d.W * 257 < (1ll << 30) && (long long)d.B * ((d.W + 3) / 4) < (1ll << 30) && d.ss0 > -(1ll << 30) && d.ss0 < (1ll << 30) &&
            d.rd_shift >= 0 && d.rd_shift < (1ll << 30);
 }
 
-template <typename T, int NR, bool MN0, bool EPI, bool WIDE, bool TBL = false>
+template <typename T, int NR, bool MN0, bool EPI, int WIDE, bool TBL = false>
 static hipError_t launch_fast_inst(T *Y, const T *X, const T *win, const T *tw, const R512FastArgs &a, hipStream_t s)
 {
     const size_t lds = (4 * (size_t)R512F_WAVE_ELEMS + 512 + 512) * sizeof(T);
@@ -540,12 +542,22 @@ hipError_t launch_stft_r512_fast(T *Y, const T *X, const T *win, const T *tw, co
     const bool epi = d.epi.any();
     const bool wide = 3 * d.stp + 512 > 1024 || (d.stp & 1);   // spans of more than 1024 samples (20 staged elements per lane), odd hops
     const bool nr13 = d.L > 384 && d.L <= 416 && !wide;
-#define DSP_R512F(NR_, MN0_, EPI_) launch_fast_inst<T, NR_, MN0_, EPI_, false>(Y, X, win, tw, a, s)
-#define DSP_R512W(MN0_, EPI_) launch_fast_inst<T, 16, MN0_, EPI_, true>(Y, X, win, tw, a, s)
-#define DSP_R512T(MN0_, EPI_) launch_fast_inst<T, 16, MN0_, EPI_, true, true>(Y, X, win, tw, a, s)
+#define DSP_R512F(NR_, MN0_, EPI_) launch_fast_inst<T, NR_, MN0_, EPI_, 0>(Y, X, win, tw, a, s)
+#define DSP_R512W(MN0_, EPI_) launch_fast_inst<T, 16, MN0_, EPI_, 1>(Y, X, win, tw, a, s)
+#define DSP_R512X(MN0_, EPI_) launch_fast_inst<T, 16, MN0_, EPI_, 2>(Y, X, win, tw, a, s)
+#define DSP_R512T(MN0_, EPI_) launch_fast_inst<T, 16, MN0_, EPI_, 1, true>(Y, X, win, tw, a, s)
+#define DSP_R512U(MN0_, EPI_) launch_fast_inst<T, 16, MN0_, EPI_, 2, true>(Y, X, win, tw, a, s)
+    if (d.tbl && d.tbl_reach + 512 > 1280) {
+        if (d.mn0) { return epi ? DSP_R512U(true, true) : DSP_R512U(true, false); }
+        return epi ? DSP_R512U(false, true) : DSP_R512U(false, false);
+    }
     if (d.tbl) {
         if (d.mn0) { return epi ? DSP_R512T(true, true) : DSP_R512T(true, false); }
         return epi ? DSP_R512T(false, true) : DSP_R512T(false, false);
+    }
+    if (3 * d.stp + 512 > 1280) {
+        if (d.mn0) { return epi ? DSP_R512X(true, true) : DSP_R512X(true, false); }
+        return epi ? DSP_R512X(false, true) : DSP_R512X(false, false);
     }
     if (wide) {
         if (d.mn0) { return epi ? DSP_R512W(true, true) : DSP_R512W(true, false); }
@@ -559,7 +571,9 @@ hipError_t launch_stft_r512_fast(T *Y, const T *X, const T *win, const T *tw, co
     return epi ? DSP_R512F(16, false, true) : DSP_R512F(16, false, false);
 #undef DSP_R512F
 #undef DSP_R512W
+#undef DSP_R512X
 #undef DSP_R512T
+#undef DSP_R512U
 }
 
 template hipError_t launch_stft_r512_fast<float>(float *, const float *, const float *, const float *, const FrameDesc &, hipStream_t);

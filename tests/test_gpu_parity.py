@@ -100,11 +100,13 @@ def test_stft_flags(O, D, dt, generic, mn0, amp, lg):
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 def test_both_512_families_agree_with_oracle(O, D, dt):
     """nfft 512 has two kernel families; each must meet the bound on its own (W not a multiple of 4,
-    a hop above the span-staging limit, an odd hop, frame starts that are not 16-byte aligned)."""
+    hops at, below and above the span-staging limit of 512, odd hops, frame starts that are not 16-byte aligned)."""
     for (N, L, stp) in [(7013, 400, 160), (7013, 512, 33), (30000, 320, 1500), (1900, 400, 160), (700, 400, 160),
                         (9001, 400, 170), (9001, 402, 160), (9001, 399, 166),    # spans that start off 16-byte boundaries
                         (9001, 512, 256), (9001, 400, 200), (5000, 512, 172), (9001, 300, 254),   # spans of 1028 to 1280 samples
-                        (9001, 400, 161), (9001, 512, 255), (2000, 100, 1), (9001, 401, 257)]:   # odd hops; 257: above the limit
+                        (9001, 400, 161), (9001, 512, 255), (2000, 100, 1),                       # odd hops
+                        (9001, 401, 257), (20001, 400, 320), (20001, 512, 512), (20001, 480, 511), (12000, 400, 400),   # spans of up to 2048 samples
+                        (20001, 512, 513), (30000, 100, 777)]:                                    # above the span-staging limit
         x = signal(N, N, dt)
         win = D.povey(L, dt)
         rc, Yref = O.stft(x, win, stp, 512, 0)
@@ -283,14 +285,15 @@ def test_stft_flt_other_sizes(O, D, dt):
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 def test_stft_flt_start_tables_512_batched(O, D, dt):
     """nfft 512 with non-integral hops on a batch: frame starts that are not equally spaced go through the
-    span-staging kernel while frames w and w + 3 start at most 768 samples apart (hops up to about 255.6), and
+    span-staging kernel while frames w and w + 3 start at most 1536 samples apart (hops up to about 511.6), and
     through the general one beyond; frame counts that are no multiple of 4, frames off both ends, every flag."""
     import torch
     B, N = 5, 40000
     xh = np.stack([signal(40 + b, N, dt) for b in range(B)])
     x = torch.from_numpy(xh).cuda()
     for (L, c0, stp, W, flags) in [(400, 200.0, 160.5, 246, (0, 0, 0)), (400, -333.0, 160.5, 251, (1, 0, 0)), (512, 256.0, 255.6, 153, (0, 1, 1)),
-                                   (512, 100.0, 256.4, 155, (0, 0, 0)), (300, 39000.0, 77.77, 41, (1, 1, 0)), (400, 7.0, 1.3, 1021, (0, 0, 1))]:
+                                   (512, 100.0, 256.4, 155, (0, 0, 0)), (300, 39000.0, 77.77, 41, (1, 1, 0)),
+                                   (400, 200.0, 300.25, 131, (0, 0, 0)), (512, 0.0, 511.6, 77, (1, 0, 1)), (512, 300.0, 512.7, 77, (0, 0, 0)), (400, 7.0, 1.3, 1021, (0, 0, 1))]:
         win = D.povey(L, dt)
         for intended in (False, True):
             D.set_flt_mode(intended)

@@ -28,3 +28,23 @@ for hop in (320, 400):
     b.record(); torch.cuda.synchronize()
     ms = a.elapsed_time(b) / 20
     print(f'stft float32 L 400 hop {hop}: {ms:.3f} ms  {1024 * y.shape[1] * (hop + 257) * 4 / ms / 8e9 * 100:.1f} % of 8 TB/s')
+# the same in float64 (512 signals)
+for hop in (320, 400):
+    x = torch.randn((512, 160000), device='cuda', dtype=torch.float64) * 0.1
+    win = torch.from_numpy(dsp_amd.hann(400, np.float64)).cuda()
+    y = dsp_amd.stft_dev(x, win, hop)
+    for _ in range(20): dsp_amd.stft_dev(x, win, hop, out=y)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(20): dsp_amd.stft_dev(x, win, hop, out=y)
+    b.record(); torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / 20
+    dsp_amd.force_generic(True)
+    for _ in range(5): dsp_amd.stft_dev(x, win, hop, out=y)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(10): dsp_amd.stft_dev(x, win, hop, out=y)
+    b.record(); torch.cuda.synchronize()
+    dsp_amd.force_generic(False)
+    print(f'stft float64 L 400 hop {hop}: {ms:.3f} ms  {512 * y.shape[1] * (hop + 257) * 8 / ms / 8e9 * 100:.1f} % of 8 TB/s (generic family: {a.elapsed_time(b) / 10:.3f} ms)')

@@ -46,9 +46,8 @@ struct R4096Args {
     unsigned *take;       // run form: 8 counters (one per blockIdx % 8), zero at launch
 };
 
-// Counters of the run form: R4096_SLOTS sets of 8, used in turn by successive launches on a device and
-// cleared in the launch's stream just before it.  Launches that overlap on one device share a set only
-// if R4096_SLOTS others were started in between.
+// Counters of the run form: R4096_SLOTS sets of 8, used in turn by successive launches on a device (how a
+// set is handed out: launch_r4096_inst).
 constexpr int R4096_SLOTS = 64;
 __device__ unsigned g_r4096_take[R4096_SLOTS * 8];
 
@@ -608,8 +607,20 @@ bool r4096_supported(const FrameDesc &d)
     return d.nfft == 4096 && d.L >= 1 && d.L <= 4096 && (long long)d.B * d.W < (1ll << 31) - 4096;
 }
 
+// Counters of the run form, one state for every instantiation: the set a launch uses, cleared in the
+// launch's stream just before it.  A set is handed out again only behind an event recorded after the
+// launch that last used it (the new launch's stream waits for that event: no host synchronisation), so two
+// launches never share counters, however many are in flight and whatever their flags.
+namespace {
+std::mutex g_take_mu;
+unsigned *g_take_base[64];
+unsigned g_take_turn[64];
+hipEvent_t g_take_ev[64][R4096_SLOTS];
+bool g_take_busy[64][R4096_SLOTS];
+}  // namespace
+
 template <bool FULL, bool MN0, bool EPI, bool RUN>
-static hipError_t launch_r4096_inst(float *Y, const float *X, const float *win, const float *tw, const R4096Args &a, hipStream_t s)
+static hipError_t launch_r4096_inst(float *Y, const float *X, const float *win, const float *tw, const R4096Args &a, hipStream_t s, unsigned *take)
 {
     const size_t lds = 4096 * sizeof(float) + (size_t)R4096_WAVES * R4096_WAVE_C * sizeof(float2) + (RUN ? (256 + 64 * 8) * sizeof(float2) : 0);
     static LdsGrant grant;
@@ -618,27 +629,40 @@ static hipError_t launch_r4096_inst(float *Y, const float *X, const float *win, 
     if (grid > 256) { grid = 256; }                      // one 8-wave workgroup per CU (151 KB of LDS each)
     grid = (grid + 7) & ~7ll;
     R4096Args b = a;
+    if (RUN && take) {
+        // the caller's counters (it answers for launches that overlap)
+        b.take = take;
+        if (hipError_t e = hipMemsetAsync(b.take, 0, 8 * sizeof(unsigned), s); e != hipSuccess) { return e; }
+        hipLaunchKernelGGL((stft_r4096_kernel<FULL, MN0, EPI, RUN>), dim3((unsigned)grid), dim3(64 * R4096_WAVES), lds, s, Y, X, win, tw, b);
+        return hipGetLastError();
+    }
     if (RUN) {
-        static std::mutex mu;
-        static unsigned *base[64];
-        static unsigned turn[64];
         int dev = 0;
         if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) { return e; }
         if (dev < 0 || dev >= 64) { return hipErrorInvalidDevice; }
-        {
-            std::lock_guard<std::mutex> lock(mu);
-            if (!base[dev]) {
-                if (hipError_t e = hipGetSymbolAddress(reinterpret_cast<void **>(&base[dev]), HIP_SYMBOL(g_r4096_take)); e != hipSuccess) { return e; }
-            }
-            b.take = base[dev] + 8 * (turn[dev]++ % R4096_SLOTS);
+        std::lock_guard<std::mutex> lock(g_take_mu);
+        if (!g_take_base[dev]) {
+            if (hipError_t e = hipGetSymbolAddress(reinterpret_cast<void **>(&g_take_base[dev]), HIP_SYMBOL(g_r4096_take)); e != hipSuccess) { return e; }
         }
+        const int slot = (int)(g_take_turn[dev]++ % R4096_SLOTS);
+        hipEvent_t &ev = g_take_ev[dev][slot];
+        if (!ev) {
+            if (hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming); e != hipSuccess) { return e; }
+        } else if (g_take_busy[dev][slot]) {
+            if (hipError_t e = hipStreamWaitEvent(s, ev, 0); e != hipSuccess) { return e; }
+        }
+        b.take = g_take_base[dev] + 8 * slot;
         if (hipError_t e = hipMemsetAsync(b.take, 0, 8 * sizeof(unsigned), s); e != hipSuccess) { return e; }
+        hipLaunchKernelGGL((stft_r4096_kernel<FULL, MN0, EPI, RUN>), dim3((unsigned)grid), dim3(64 * R4096_WAVES), lds, s, Y, X, win, tw, b);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) { return e; }
+        g_take_busy[dev][slot] = true;
+        return hipEventRecord(ev, s);
     }
     hipLaunchKernelGGL((stft_r4096_kernel<FULL, MN0, EPI, RUN>), dim3((unsigned)grid), dim3(64 * R4096_WAVES), lds, s, Y, X, win, tw, b);
     return hipGetLastError();
 }
 
-hipError_t launch_stft_r4096(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, hipStream_t s)
+hipError_t launch_stft_r4096(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, hipStream_t s, unsigned *take)
 {
     R4096Args a{};
     a.ldx = d.ldx; a.N = d.N; a.ss0 = d.ss0; a.rd_shift = d.rd_shift; a.tbl = d.tbl;
@@ -652,7 +676,7 @@ hipError_t launch_stft_r4096(float *Y, const float *X, const float *win, const f
     if (const char *e = getenv("DSP_R4096_MIN_RUNS")) { min_runs = atoll(e) > 0 ? atoll(e) : (1ll << 62); }
     const long long runs = (long long)d.B * ((d.W + R4096_RUN - 1) / R4096_RUN);
     const bool run = full && d.tbl == nullptr && d.stp == 1024 && runs >= min_runs;
-#define DSP_R4096(F_, M_, E_, R_) launch_r4096_inst<F_, M_, E_, R_>(Y, X, win, tw, a, s)
+#define DSP_R4096(F_, M_, E_, R_) launch_r4096_inst<F_, M_, E_, R_>(Y, X, win, tw, a, s, take)
     if (run) {
         if (d.mn0) { return epi ? DSP_R4096(true, true, true, true) : DSP_R4096(true, true, false, true); }
         return epi ? DSP_R4096(true, false, true, true) : DSP_R4096(true, false, false, true);

@@ -239,27 +239,30 @@ int family_of(size_t nfft)
     return 2;
 }
 
+// tw_fixed / take: a caller-held twiddle table of nfft (power of two) and run-form counters, in place of the
+// library's cached table and counter sets (the allocation-free entry point)
 template <typename T>
-int run_fused(const char *fn, int dev, T *Yd, const T *Xd, const T *wd, const FrameDesc &d, hipStream_t s)
+int run_fused(const char *fn, int dev, T *Yd, const T *Xd, const T *wd, const FrameDesc &d, hipStream_t s,
+              const T *tw_fixed = nullptr, unsigned *take = nullptr)
 {
     if (d.W == 0 || d.B == 0) { return 0; }
     const size_t nfft = (size_t)d.nfft;
     const int fam = family_of<T>(nfft);
-    const T *tw = nullptr;
+    const T *tw = tw_fixed;
     if (fam == 1) {
         if ((size_t)d.L * sizeof(T) > LDS_LIMIT) { fprintf(stderr, "error in %s: L too large for a non-power-of-two nfft (limit %zu)\n", fn, LDS_LIMIT / sizeof(T)); return 1; }
         if (get_twiddles<T>(fn, dev, nfft, 1, tw)) { return 1; }
         HIPCHK(fn, launch_stft_direct<T>(Yd, Xd, wd, tw, d, s));
         return 0;
     }
-    if (get_twiddles<T>(fn, dev, nfft, 0, tw)) { return 1; }
+    if (!tw && get_twiddles<T>(fn, dev, nfft, 0, tw)) { return 1; }
     if (fam == 3 && r512_supported<T>(d)) {
         HIPCHK(fn, launch_stft_r512<T>(Yd, Xd, wd, tw, d, s));
         return 0;
     }
     if constexpr (sizeof(T) == 4) {
         if (fam == 4 && r4096_supported(d)) {
-            HIPCHK(fn, launch_stft_r4096(Yd, Xd, wd, tw, d, s));
+            HIPCHK(fn, launch_stft_r4096(Yd, Xd, wd, tw, d, s, take));
             return 0;
         }
     }
@@ -348,6 +351,74 @@ int stft_flt_dev(const char *fn, T *Yd, const T *Xd, const T *wd, size_t B, size
     if (use_device(fn, dev)) { return 1; }
     if (flt_desc<T>(fn, dev, d, B, N, ldx, L, W, nfft, c0, stp, mn0, amp, lg, !g_flt_intended.load(), true)) { return 1; }
     return run_fused<T>(fn, dev, Yd, Xd, wd, d, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// allocation-free form of the batched device-resident STFT (float32, nfft a power of two <= 4096)
+// ------------------------------------------------------------------------------------------------
+// What the kernels need beyond the caller's input and output lives in one array of the code object
+// instead of hipMalloc'ed memory: the twiddle tables of nfft = 2, 4, ..., 4096 (nfft floats each, the table
+// of nfft at float offset nfft - 2) and, behind them, the 8 work counters of the 4096-point run form.
+// Every device holds its own copy at its own address, found once per device with hipGetSymbolAddress
+// while that device is current; host code passes that address, never the array's name.
+constexpr size_t NA_MAX_NFFT = 4096;
+constexpr size_t NA_TW_BYTES = 2 * NA_MAX_NFFT * sizeof(float);    // 8190 floats used
+constexpr size_t NA_SCRATCH_BYTES = NA_TW_BYTES + 256;             // + the counters (32 bytes used)
+static __device__ __align__(256) unsigned char scratch[NA_SCRATCH_BYTES];
+
+// complex entry c of the tables, c < 4095: table nfft = 2 h with h the largest power of two <= c + 1,
+// k = c + 1 - h; value (cos, -sin)(2 pi k / nfft) evaluated in double and rounded once
+__global__ void na_fill_twiddles(float *tw)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int)NA_MAX_NFFT - 1) { return; }
+    const int m = c + 1, h = 1 << (31 - __clz(m)), k = m - h;
+    double sn, cs;
+    sincospi((double)k / (double)h, &sn, &cs);                    // 2 pi k / (2 h) = pi k / h
+    tw[2 * c] = (float)cs;
+    tw[2 * c + 1] = (float)(-sn);
+}
+
+struct NaDev { std::mutex mu; unsigned char *ptr = nullptr; };
+NaDev g_na[MAX_DEV];
+
+// address of the device's copy of the array; on the first call for a device the tables are computed by a
+// kernel in the caller's stream, which is waited for once so that calls on other streams find them complete
+int na_setup(const char *fn, int dev, hipStream_t s, unsigned char *&ptr)
+{
+    NaDev &st = g_na[dev];
+    std::lock_guard<std::mutex> lk(st.mu);
+    if (!st.ptr) {
+        void *p = nullptr;
+        HIPCHK(fn, hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        hipLaunchKernelGGL(na_fill_twiddles, dim3((NA_MAX_NFFT + 255) / 256), dim3(256), 0, s, static_cast<float *>(p));
+        HIPCHK(fn, hipGetLastError());
+        HIPCHK(fn, hipStreamSynchronize(s));
+        st.ptr = static_cast<unsigned char *>(p);
+    }
+    ptr = st.ptr;
+    return 0;
+}
+
+int stft_dev_noalloc(const char *fn, float *Yd, const float *Xd, const float *wd, size_t B, size_t N, size_t ldx, size_t L, size_t nfft,
+                     size_t stp, int snip_edges, int mn0, int amp, int lg, void *stream)
+{
+    FrameDesc d; size_t W;
+    if (stft_desc(fn, d, B, N, ldx, L, nfft, stp, snip_edges, mn0, amp, lg, W)) { return 1; }
+    if (!is_pow2(nfft) || nfft > NA_MAX_NFFT) {
+        fprintf(stderr, "error in %s: nfft must be a power of two <= %zu (the limit of the allocation-free form)\n", fn, NA_MAX_NFFT);
+        return 1;
+    }
+    if (W == 0 || B == 0) { return 0; }
+    if (B > 1 && ldx < N) { fprintf(stderr, "error in %s: ldx must be >= N\n", fn); return 1; }
+    if (!Yd || !Xd || !wd) { fprintf(stderr, "error in %s: null device pointer\n", fn); return 1; }
+    int dev;
+    if (use_device(fn, dev)) { return 1; }
+    unsigned char *base = nullptr;
+    if (na_setup(fn, dev, (hipStream_t)stream, base)) { return 1; }
+    const float *tw = reinterpret_cast<const float *>(base) + (nfft - 2);
+    unsigned *take = reinterpret_cast<unsigned *>(base + NA_TW_BYTES);
+    return run_fused<float>(fn, dev, Yd, Xd, wd, d, (hipStream_t)stream, tw, take);
 }
 
 // power compression as an epilogue; checks and messages of reference c/pow_compress.c:25-26,30-46
@@ -848,6 +919,9 @@ int dsp_stft_batch_dev_s(float *Y_dev, const float *X_dev, const float *win_dev,
 { return stft_dev<float>("dsp_stft_batch_dev_s", Y_dev, X_dev, win_dev, B, N, ldx, L, nfft, stp, snip_edges, mn0, amp, lg, stream); }
 int dsp_stft_batch_dev_d(double *Y_dev, const double *X_dev, const double *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, void *stream)
 { return stft_dev<double>("dsp_stft_batch_dev_d", Y_dev, X_dev, win_dev, B, N, ldx, L, nfft, stp, snip_edges, mn0, amp, lg, stream); }
+
+int dsp_stft_batch_dev_noalloc_s(float *Y_dev, const float *X_dev, const float *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, void *stream)
+{ return stft_dev_noalloc("dsp_stft_batch_dev_noalloc_s", Y_dev, X_dev, win_dev, B, N, ldx, L, nfft, stp, snip_edges, mn0, amp, lg, stream); }
 
 int dsp_stft_flt_batch_dev_s(float *Y_dev, const float *X_dev, const float *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t W, const size_t nfft, const float c0, const float stp, const int mn0, const int amp, const int lg, void *stream)
 { return stft_flt_dev<float>("dsp_stft_flt_batch_dev_s", Y_dev, X_dev, win_dev, B, N, ldx, L, W, nfft, c0, stp, mn0, amp, lg, stream); }

@@ -173,6 +173,17 @@ int dsp_stft_flt_set_mode (const int intended);
 int dsp_stft_batch_dev_s (float *Y_dev, const float *X_dev, const float *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, void *stream);
 int dsp_stft_batch_dev_d (double *Y_dev, const double *X_dev, const double *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, void *stream);
 
+/* No counterpart in the reference.  dsp_stft_batch_dev_s for callers that cannot allocate device memory
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): float32, nfft a
+ * power of two <= 4096 (any other nfft returns 1 with an error line).  It calls no hipMalloc / hipFree:
+ * the twiddle tables and the work counters its kernels use live in one 33 KB array of the library's code
+ * object (each device the library runs on holds its copy until the process ends).  The first call on a
+ * device computes the tables with a kernel in `stream` and waits for that stream once; later calls only
+ * enqueue.  Every call on a device shares that array: the counters are cleared in `stream` before each
+ * 4096-point launch, so calls that OVERLAP on one device (different streams) race; calls in one stream,
+ * or one after another, do not.  Same arguments, output and error behaviour as dsp_stft_batch_dev_s. */
+int dsp_stft_batch_dev_noalloc_s (float *Y_dev, const float *X_dev, const float *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, void *stream);
+
 /* Batched, device-resident stft_flt (same conventions; W frames per signal). */
 int dsp_stft_flt_batch_dev_s (float *Y_dev, const float *X_dev, const float *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t W, const size_t nfft, const float c0, const float stp, const int mn0, const int amp, const int lg, void *stream);
 int dsp_stft_flt_batch_dev_d (double *Y_dev, const double *X_dev, const double *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t W, const size_t nfft, const double c0, const double stp, const int mn0, const int amp, const int lg, void *stream);

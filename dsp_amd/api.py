@@ -54,6 +54,13 @@ def _check(rc, name):
         raise DspError(f"{name} failed (see stderr)")
 
 
+def _check_out(out, shape, like, what):
+    """A caller-supplied device output must be exactly what the kernel writes: a wrong shape, dtype, device or
+    layout would make it write past the tensor."""
+    if tuple(out.shape) != tuple(shape) or not out.is_contiguous() or out.dtype != like.dtype or out.device != like.device:
+        raise ValueError(f"out must be a contiguous {what} tensor of x's dtype on x's device")
+
+
 def stft(x, win, stp=160, snip_edges=False, mn0=False, amp=False, lg=False, nfft=None):
     """stft_s / stft_d.  x: 1-D signal, win: 1-D window; returns Y[W, nfft//2+1]."""
     x = np.ascontiguousarray(x)
@@ -357,8 +364,8 @@ def stft_dev(x, win, stp=160, snip_edges=False, mn0=False, amp=False, lg=False, 
     W = num_frames(N, L, stp, snip_edges)
     if out is None:
         out = torch.empty((B, W, nfft // 2 + 1), dtype=x.dtype, device=x.device)
-    elif tuple(out.shape) != (B, W, nfft // 2 + 1) or not out.is_contiguous() or out.dtype != x.dtype:
-        raise ValueError("out must be a contiguous [B, W, F] tensor of x's dtype")
+    else:
+        _check_out(out, (B, W, nfft // 2 + 1), x, "[B, W, F]")
     with torch.cuda.device(x.device):
         rc = getattr(lib(), f"dsp_stft_batch_dev_{s}")(C.c_void_p(out.data_ptr()), C.c_void_p(x.data_ptr()),
                                                        C.c_void_p(win.data_ptr()), B, N, ldx, L, nfft, stp,
@@ -384,8 +391,8 @@ def stft_pc_dev(x, win, p, preg=0.0, stp=160, snip_edges=False, mn0=False, amp=F
     W = num_frames(N, L, stp, snip_edges)
     if out is None:
         out = torch.empty((B, W, nfft // 2 + 1), dtype=x.dtype, device=x.device)
-    elif tuple(out.shape) != (B, W, nfft // 2 + 1) or not out.is_contiguous() or out.dtype != x.dtype:
-        raise ValueError("out must be a contiguous [B, W, F] tensor of x's dtype")
+    else:
+        _check_out(out, (B, W, nfft // 2 + 1), x, "[B, W, F]")
     with torch.cuda.device(x.device):
         rc = getattr(lib(), f"dsp_stft_pc_batch_dev_{s}")(C.c_void_p(out.data_ptr()), C.c_void_p(x.data_ptr()),
                                                           C.c_void_p(win.data_ptr()), B, N, ldx, L, nfft, stp,
@@ -403,6 +410,8 @@ def pow_compress_dev(x, p, preg=0.0, out=None):
     s = _torch_sfx(x)
     if out is None:
         out = torch.empty_like(x)
+    else:
+        _check_out(out, x.shape, x, "x-shaped")
     with torch.cuda.device(x.device):
         rc = getattr(lib(), f"dsp_pow_compress_dev_{s}")(C.c_void_p(out.data_ptr()), C.c_void_p(x.data_ptr()), x.numel(),
                                                          float(p), float(preg), _stream_ptr(x))
@@ -425,6 +434,8 @@ def stft_flt_dev(x, win, W, c0=0.0, stp=160.0, mn0=False, amp=False, lg=False, n
     nfft = nextpow2(L) if nfft is None else int(nfft)
     if out is None:
         out = torch.empty((B, W, nfft // 2 + 1), dtype=x.dtype, device=x.device)
+    else:
+        _check_out(out, (B, W, nfft // 2 + 1), x, "[B, W, F]")
     with torch.cuda.device(x.device):
         rc = getattr(lib(), f"dsp_stft_flt_batch_dev_{s}")(C.c_void_p(out.data_ptr()), C.c_void_p(x.data_ptr()),
                                                            C.c_void_p(win.data_ptr()), B, N, ldx, L, W, nfft, c0, stp,
@@ -438,8 +449,11 @@ def fft_power_dev(xc, out=None):
     import torch
     xc = xc.contiguous()
     s = {torch.complex64: "c", torch.complex128: "z"}[xc.dtype]
+    rdt = torch.float32 if s == "c" else torch.float64
     if out is None:
-        out = torch.empty(xc.shape, dtype=torch.float32 if s == "c" else torch.float64, device=xc.device)
+        out = torch.empty(xc.shape, dtype=rdt, device=xc.device)
+    elif tuple(out.shape) != tuple(xc.shape) or not out.is_contiguous() or out.dtype != rdt or out.device != xc.device:
+        raise ValueError("out must be a contiguous real tensor of xc's shape and precision on xc's device")
     with torch.cuda.device(xc.device):
         rc = getattr(lib(), f"dsp_fft_power_dev_{s}")(C.c_void_p(out.data_ptr()), C.c_void_p(xc.data_ptr()), xc.numel(),
                                                       _stream_ptr(xc))

@@ -1,14 +1,19 @@
 // Fast path of the 512-point fused STFT kernel for gfx950: integer hop with 3*hop + 512 <= 2048 (hop <= 512),
 // frames addressed as start = ss0 + w*hop (the stft framing, and the stft_flt framing when
 // its hop is integral), or (TBL) frames whose starts come from a table, never decrease and lie at most 1536
-// samples apart for frames w and w + 3 (the stft_flt framing with a non-integral hop).  Same arithmetic as the basic kernel in r512_kernel.hip; what differs is the
+// samples apart for frames w and w + 3 (the stft_flt framing with a non-integral hop).  Same arithmetic as the
+// basic kernel in r512_kernel.hip (16 lanes per frame, 4 frames = one step per wavefront); what differs is the
 // schedule around it:
-//   * the span of the next 4 frames is fetched from HBM into registers (16-byte loads) while the
-//     current 4 frames are transformed, and is committed to LDS at the top of the next step, so the
-//     HBM latency is off the critical path; every input sample is fetched once per run of frames;
-//   * the staged span and the 16 x 16 exchange tile share one LDS region (8.7 KB per wave in
-//     float); two workgroups of four waves run on a CU (the registers, not the LDS, set that), swap
-//     issue priority every step and keep their waves in step with a barrier every fourth step;
+//   * one workgroup of 8 waves per CU (two per SIMD: the registers set that).  The steps of the batch are cut
+//     into 8 contiguous ranges, one per group of workgroups that share an XCD, a workgroup owns 8 neighbouring
+//     steps of every round of its range, and its waves DRAW those steps from a counter in LDS.  (The two
+//     waves of a SIMD do not run at one pace, the older one issues first: dealt statically, one per
+//     wave and round, the slower half of the waves ended 6 % after the faster half.)
+//   * the span of the next step is fetched while the current one is transformed.  float, equally spaced
+//     frames (RING): by LDS-DMA (global_load_lds_dwordx4) straight into a span slot of the wave's own, issued as
+//     soon as pass 1 has read the slot; no registers, no LDS write pass, and the counted wait for it leaves the
+//     step's row stores in flight.  Otherwise (double: no LDS left for slots; table form): into registers
+//     (16-byte loads), committed to LDS at the top of the next step, where the span shares the exchange tile;
 //   * rows leave as 16-byte non-temporal stores of the step's 4 x 257 values, staged through LDS in
 //     the order they have in the output;
 //   * the compile-time shape (rows of the window that hold data, mean removal, sqrt/log epilogue)
@@ -32,9 +37,11 @@ struct R512FastArgs {
     int sps;              // steps (groups of 4 consecutive frames) per signal
     int steps;            // B * sps
     const int *tbl;       // table form: start of frame w at tbl[2 w] (frames need not be equally spaced)
+    int all16;            // every step has 4 frames and its block of rows is 16-byte aligned
 };
 
-constexpr int R512F_WAVE_ELEMS = 4 * R512_EXF * 2;   // T elements of LDS per wave (>= 1280 staged samples)
+constexpr int R512F_WAVE_ELEMS = 4 * R512_EXF * 2;   // T elements of a wave's exchange tile (>= 2048: the longest span)
+constexpr int R512F_WAVES = 8;                        // waves per workgroup
 
 // value of lane (16 - i) % 16 of the same 16-lane row (row_mirror, then row_ror:1)
 __device__ __forceinline__ int dpp_partner16_i(int v)
@@ -65,22 +72,13 @@ template <> struct vec16u<double> { typedef double type __attribute__((ext_vecto
 #ifndef R512F_WIN_LDS
 #define R512F_WIN_LDS 0         // 1: float window taps come from LDS too (double always does)
 #endif
-#ifndef R512F_ABLATE
-#define R512F_ABLATE 0          // diagnostic builds: 1 = memory traffic only, 2 = no scalar-path stores, 3 = no FFT arithmetic, 4 = no exchange through LDS
-#endif
 #ifndef R512F_NT_STORE
 #define R512F_NT_STORE 1        // 1: spectrogram rows are stored with the non-temporal hint
-#endif
-#ifndef R512F_NT_LOAD
-#define R512F_NT_LOAD 0         // 1: signal spans are loaded with the non-temporal hint
 #endif
 #if R512F_NT_STORE
 #define R512F_ST(ptr, val) __builtin_nontemporal_store((val), (ptr))
 #else
 #define R512F_ST(ptr, val) (*(ptr) = (val))
-#endif
-#ifndef R512F_ALT_PRIO
-#define R512F_ALT_PRIO 1        // 1 = the two workgroups of a CU swap issue priority every step
 #endif
 #ifndef R512F_STAMPS
 #define R512F_STAMPS 0          // diagnostic builds: 1 = per-phase s_memtime sums into g_r512f_stamps
@@ -107,20 +105,53 @@ __device__ unsigned long long g_r512f_stamps[8192 * 8];
 #ifndef R512F_NOSTORE
 #define R512F_NOSTORE 0         // diagnostic builds: 1 = the row stores are compiled out
 #endif
-#ifndef R512F_LOCK_EVERY
-#define R512F_LOCK_EVERY 4      // n > 0 (power of two): the waves of a workgroup meet at a barrier every n steps
-#endif
 #ifndef R512F_ST4
 #define R512F_ST4 1             // 1: rows leave as 16-byte vector stores when the step's block is 16-byte aligned
 #endif
-#ifndef R512F_MINWAVES_F32
-#define R512F_MINWAVES_F32 2
+#ifndef R512F_RING_F32
+#define R512F_RING_F32 1        // 1: float, equally spaced frames: the next span comes by LDS-DMA into a slot of its own
+#endif
+#ifndef R512F_TWLDS_SEL
+#define R512F_TWLDS_SEL (WIDE == 2)   // float instantiations whose pass-1 twiddles come from LDS: 2048-sample spans (registers run out: measured +7 % from LDS, and 1.4x for the table form, which spilled)
+#endif
+#ifndef R512F_MINIMAL
+#define R512F_MINIMAL 0         // diagnostic builds: 1 = only the benchmark's instantiation is compiled (seconds instead of minutes)
 #endif
 
-template <typename T, int NR, bool MN0, bool EPI, int WIDE, bool TBL>
-__global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) void stft_r512_fast_kernel(T *__restrict__ Y, const T *__restrict__ X,
-                                                              const T *__restrict__ win, const T *__restrict__ tw,
-                                                              const R512FastArgs a)
+// One 16-byte-per-lane LDS-DMA load (1 KiB per wave: lane i's 16 bytes land at lds + 16 i).  Written in
+// assembly so that the compiler's wait counting does not see it (it would wait for ALL outstanding memory
+// operations, the row stores included, before the first read of the span): the kernel waits for a span
+// with a counted s_waitcnt itself.  lds: wave-uniform LDS byte address.
+__device__ __forceinline__ void r512f_glds16(const void *g, const unsigned lds)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds) : "memory");
+}
+__device__ __forceinline__ unsigned r512f_lds_addr(const void *p)
+{
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
+}
+template <int N> __device__ __forceinline__ void r512f_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// Draw of a step: lane 0 alone adds 1 to the workgroup's counter (LDS byte address `cnt`); the old value is in
+// lane 0 of `t` once r512f_drawn has waited for it.  In assembly for the same reason as the load above: the
+// compiler's form waits for the answer on the spot.
+__device__ __forceinline__ void r512f_draw(unsigned &t, const unsigned cnt)
+{
+    unsigned long long keep;
+    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tds_add_rtn_u32 %0, %2, %3\n\ts_mov_b64 exec, %1"
+                 : "=&v"(t), "=&s"(keep) : "v"(cnt), "v"(1u) : "memory");
+}
+__device__ __forceinline__ int r512f_drawn(unsigned &t)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t) :: "memory");
+    return (int)__builtin_amdgcn_readfirstlane(t);
+}
+
+template <typename T, int NR, bool MN0, bool EPI, int WIDE, bool TBL, bool RING>
+__global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *__restrict__ Y, const T *__restrict__ X,
+                                                                             const T *__restrict__ win, const T *__restrict__ tw,
+                                                                             const R512FastArgs a)
 {
     using T2 = typename vec2<T>::type;
     using TV = typename vec16<T>::type;
@@ -128,19 +159,26 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
     // WIDE 2: 32 (2048: hop <= 512)
     constexpr int VEC = vec16<T>::n, SPAN = WIDE == 2 ? 2048 : WIDE ? 1280 : 1024, NV = SPAN / 64 / VEC;
     static_assert(SPAN <= R512F_WAVE_ELEMS, "the staged span lives in the wave's exchange region");
+    static_assert(!RING || !TBL, "the LDS-DMA form takes equally spaced frames");
+    constexpr int WAVE_LDS = R512F_WAVE_ELEMS + (RING ? SPAN : 0);
     constexpr bool WINREG = (sizeof(T) == 4) && !R512F_WIN_LDS;
-    constexpr bool TWREG = !R512F_TW_LDS && !(R512F_TW_LDS_F64 && sizeof(T) == 8);
-    constexpr int M = 256, F = 257;
+    // pass-1 twiddles in registers, except where they do not fit beside the other state (double; spans of 2048
+    // samples): there they are read from an LDS table
+    constexpr bool TWREG = !R512F_TW_LDS && !(R512F_TW_LDS_F64 && sizeof(T) == 8) && !(R512F_TWLDS_SEL);
+    constexpr int M = 256, F = 257, NWV = R512F_WAVES;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int f = lane >> 4, j = lane & 15;
     const int L = a.L;
 
-    T *xs = reinterpret_cast<T *>(smem_raw) + wv * R512F_WAVE_ELEMS;   // staged span; aliases the exchange tile
+    T *xs = reinterpret_cast<T *>(smem_raw) + wv * WAVE_LDS;           // exchange tile and row staging; !RING: the staged span too
     T2 *ex = reinterpret_cast<T2 *>(xs);
-    T *wtab = reinterpret_cast<T *>(smem_raw) + 4 * R512F_WAVE_ELEMS;  // halved window, 512 T
+    T *slot = xs + R512F_WAVE_ELEMS;                                   // RING: the span slot
+    T *wtab = reinterpret_cast<T *>(smem_raw) + NWV * WAVE_LDS;        // halved window, 512 T
     T2 *ttab = reinterpret_cast<T2 *>(wtab + 512);                     // W256^(j k1) at [k1][j], 256 T2
+    T *dummy = reinterpret_cast<T *>(ttab + 256);                      // RING: 1 KiB that placeholder LDS-DMA loads write
+    unsigned *ticket = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(dummy) + 1024);   // the next draw
 
     // ---- per-lane constants ----
     using C = cx<T>;
@@ -153,7 +191,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
             if (idx >= 256) { idx -= 256; sg = T(-1); }
             twd[k1] = C{sg * tw[2 * idx], sg * tw[2 * idx + 1]};
         }
-    } else {
+    } else if (tid < 256) {
         const int k1 = tid >> 4, jj = tid & 15;
         int idx = 2 * jj * k1;
         T sg = T(1);
@@ -172,32 +210,68 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
             hw[n1] = C{(l < L) ? T(0.5) * win[l] : T(0), (l + 1 < L) ? T(0.5) * win[l + 1] : T(0)};
         }
     } else {
-        for (int l = tid; l < 512; l += 256) { wtab[l] = (l < L) ? T(0.5) * win[l] : T(0); }
+        for (int l = tid; l < 512; l += 64 * NWV) { wtab[l] = (l < L) ? T(0.5) * win[l] : T(0); }
     }
-    if (!WINREG || !TWREG) { __syncthreads(); }
+    if (tid == 0) { *ticket = NWV; }                         // the first 8 steps go to the waves in order
+    __syncthreads();
     static_assert(!TBL || (WIDE >= 1 && NR == 16), "the table form uses the wide, 16-row instantiations");
     const int reach = TBL ? a.stp : 3 * a.stp;               // start of the step's last frame relative to its first
     const int need = reach + 512;
     const int nvec = (reach + 32 * NR + VEC - 1) / VEC;      // 16-byte vectors of a span that pass 1 reads
-    const T *xrow = xs + f * a.stp + 2 * j;                  // (table form: set per step)
+    const T *xrow = (RING ? slot : xs) + f * a.stp + 2 * j;  // (table form: set per step)
     // table form: lane i holds the start of frame w + (i & 3) of a step (clamped to the last frame)
     auto tbl_fetch = [&](const int w_) { return a.tbl[2 * min(w_ + (lane & 3), a.W - 1)]; };
     auto tbl_xrow = [&](const int tv) { return xs + (__shfl(tv, f) - __builtin_amdgcn_readfirstlane(tv)) + 2 * j; };
 
-    // ---- fetch of one span (frames w..w+3 of the signal at xb) into registers ----
-    TV pre[NV];
+    // ---- fetch of one span (frames w..w+3 of the signal at xb): into registers, or (RING) into the slot.
+    // A span that crosses an edge of its signal (reflection or zeros) is gathered sample by sample.
+    TV pre[RING ? 1 : NV];
+    auto gather = [&](const T *xb, const int s0, const int q, TV &out) {
+        FrameDesc d{};
+        d.N = a.N; d.edge = a.edge;
+        T t[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const int i = (q * 64 + lane) * VEC + v;
+            t[v] = (i < need) ? fetch_sample(xb, d, (long long)s0, (long long)a.rd_shift, i) : T(0);
+        }
+        if constexpr (VEC == 4) { out = TV{t[0], t[1], t[2], t[3]}; }
+        else { out = TV{t[0], t[1]}; }
+    };
     auto load_span = [&](const T *xb, const int s0) {
         const T *src = xb + (s0 - (a.edge ? a.rd_shift : 0));
         const bool inside = s0 >= 0 && s0 + SPAN <= a.N && (a.edge == 0 || s0 >= a.rd_shift);
-        if (inside && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+        if constexpr (RING) {
+            // NV LDS-DMA loads per span whatever the case (the counted wait relies on that): behind a gathered
+            // span NV placeholder loads follow, from the twiddle table into `dummy`
+            if (inside) {
+#pragma unroll
+                for (int q = 0; q < NV; ++q) {
+                    // only 3*hop + 32*NR samples are ever read by pass 1: lanes past that re-read the last needed vector
+#if R512F_NOLOAD
+                    r512f_glds16(tw + lane * VEC, __builtin_amdgcn_readfirstlane(r512f_lds_addr(dummy)));
+#else
+                    r512f_glds16(src + min(q * 64 + lane, nvec - 1) * VEC, __builtin_amdgcn_readfirstlane(r512f_lds_addr(slot + q * 64 * VEC)));
+#endif
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NV; ++q) {
+                    TV v;
+                    gather(xb, s0, q, v);
+                    reinterpret_cast<TV *>(slot)[q * 64 + lane] = v;
+                }
+#pragma unroll
+                for (int q = 0; q < NV; ++q) { r512f_glds16(tw + lane * VEC, __builtin_amdgcn_readfirstlane(r512f_lds_addr(dummy))); }
+            }
+        } else if (inside && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
 #pragma unroll
             for (int q = 0; q < NV; ++q) {
-                // only 3*hop + 32*NR samples are ever read by pass 1: lanes past that re-read the last
-                // needed vector (same cache line, no extra traffic) so that the number of loads stays fixed
+                // lanes past the last needed vector re-read it (same cache line, no extra traffic): the number of loads stays fixed
 #if R512F_NOLOAD
                 if (a.N == -12345)
 #endif
-                pre[q] = reinterpret_cast<const TV *>(src)[min(q * 64 + lane, nvec - 1)];
+                pre[RING ? 0 : q] = reinterpret_cast<const TV *>(src)[min(q * 64 + lane, nvec - 1)];
             }
         } else if (inside) {
             // a span that does not start on a 16-byte boundary (odd ss0, a hop that is no multiple of 4
@@ -206,48 +280,41 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
 #pragma unroll
             for (int q = 0; q < NV; ++q) {
                 const TVu v = reinterpret_cast<const TVu *>(src)[min(q * 64 + lane, nvec - 1)];
-                if constexpr (VEC == 4) { pre[q] = TV{v.x, v.y, v.z, v.w}; }
-                else { pre[q] = TV{v.x, v.y}; }
+                if constexpr (VEC == 4) { pre[RING ? 0 : q] = TV{v.x, v.y, v.z, v.w}; }
+                else { pre[RING ? 0 : q] = TV{v.x, v.y}; }
             }
         } else {
-            FrameDesc d{};
-            d.N = a.N; d.edge = a.edge;
 #pragma unroll
-            for (int q = 0; q < NV; ++q) {
-                T t[VEC];
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) {
-                    const int i = (q * 64 + lane) * VEC + v;
-                    t[v] = (i < need) ? fetch_sample(xb, d, (long long)s0, (long long)a.rd_shift, i) : T(0);
-                }
-                if constexpr (VEC == 4) { pre[q] = TV{t[0], t[1], t[2], t[3]}; }
-                else { pre[q] = TV{t[0], t[1]}; }
-            }
+            for (int q = 0; q < NV; ++q) { gather(xb, s0, q, pre[RING ? 0 : q]); }
         }
     };
 
     // Work distribution: the steps of the whole batch are cut into 8 contiguous ranges, one per group
-    // of workgroups that share an XCD (blockIdx % 8), and inside a range the waves take steps
-    // round-robin.  The waves of a range therefore read and write one moving window of adjacent
-    // addresses (good DRAM page locality, and the samples two neighbouring steps share come from the
-    // same L2) instead of thousands of separate streams.
+    // of workgroups that share an XCD (blockIdx % 8); a round of a range is 8 steps for each of its workgroups,
+    // neighbouring steps to one workgroup.  The waves of a range therefore read and write one moving window of
+    // adjacent addresses (good DRAM page locality, and the samples two neighbouring steps share come from
+    // the same L1 or L2) instead of thousands of separate streams.  Draw t of a workgroup is step t % 8 of
+    // its round t / 8: the wave that is ready first takes it.
     const int xcd = blockIdx.x & 7, nwg_x = gridDim.x >> 3;
     const int s_lo = (int)((long long)a.steps * xcd / 8), s_hi = (int)((long long)a.steps * (xcd + 1) / 8);
-    const int sstride = nwg_x * 4;
-    int sid = s_lo + (blockIdx.x >> 3) * 4 + wv;
+    const int round = nwg_x * NWV, first = s_lo + (blockIdx.x >> 3) * NWV;
+    int sid = first + wv;
     if (sid >= s_hi) { return; }
     int b = sid / a.sps;
     int w = (sid - b * a.sps) * 4;
     const T *xb = X + (long long)b * a.ldx;
     T *yb = Y + (long long)b * a.W * F;
 
-    // position of the wave's next step
+    // the wave's next step, from its latest draw
+    const unsigned cnt_addr = r512f_lds_addr(ticket);
+    unsigned drawn = 0;
     int nsid, nw;
     const T *nxb;
     T *nyb;
     bool more;
     auto advance = [&]() {
-        nsid = sid + sstride;
+        const int t = r512f_drawn(drawn);
+        nsid = first + (t >> 3) * round + (t & 7);
         more = nsid < s_hi;
         if (more) {
             const int nb = nsid / a.sps;
@@ -261,43 +328,49 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory");
 #endif
-    // prologue: first span to LDS, second span in flight (table form: the starts of its frames in
-    // flight; its span is fetched in the middle of the step, when they have arrived)
+    // prologue.  RING: the first span in flight.  Otherwise: first span to LDS, second span in flight (table
+    // form: the starts of its frames in flight; its span is fetched in the middle of the step, when they
+    // have arrived)
     int tvn = 0;
-    if constexpr (TBL) {
-        const int tv = tbl_fetch(w);
-        xrow = tbl_xrow(tv);
-        load_span(xb, __builtin_amdgcn_readfirstlane(tv));
-    } else {
+    bool first_step = true;
+    if constexpr (RING) {
         load_span(xb, a.ss0 + w * a.stp);
-    }
+    } else {
+        r512f_draw(drawn, cnt_addr);
+        if constexpr (TBL) {
+            const int tv = tbl_fetch(w);
+            xrow = tbl_xrow(tv);
+            load_span(xb, __builtin_amdgcn_readfirstlane(tv));
+        } else {
+            load_span(xb, a.ss0 + w * a.stp);
+        }
 #pragma unroll
-    for (int q = 0; q < NV; ++q) { reinterpret_cast<TV *>(xs)[q * 64 + lane] = pre[q]; }
-    wave_sync();
-    advance();
-    if constexpr (TBL) { if (more) { tvn = tbl_fetch(nw); } }
-    else { if (more) { load_span(nxb, nw * a.stp + a.ss0); } }
+        for (int q = 0; q < NV; ++q) { reinterpret_cast<TV *>(xs)[q * 64 + lane] = pre[q]; }
+        wave_sync();
+        advance();
+        if constexpr (TBL) { if (more) { tvn = tbl_fetch(nw); } }
+        else { if (more) { load_span(nxb, nw * a.stp + a.ss0); } }
+    }
 
     // Steady state per step: transform the staged span and store its rows while the next span is in
-    // flight; then commit that span to LDS and issue the fetch of the one after.  The stores of a
-    // step are unconditional and fixed in number, so the wait for the in-flight span leaves them
-    // outstanding instead of draining the store queue.
-#if R512F_LOCK_EVERY
-    int it = 0;
-#endif
+    // flight.  The stores of a step are unconditional and fixed in number, so the wait for the in-flight span
+    // leaves them outstanding instead of draining the store queue.
     while (true) {
-#if R512F_LOCK_EVERY
-        if ((it++ & (R512F_LOCK_EVERY - 1)) == 0) { __builtin_amdgcn_s_barrier(); }
-#if R512F_ALT_PRIO
-        // The two workgroups of a CU (blockIdx b and b + 256) share its SIMDs, and of two waves on a
-        // SIMD the older one issues first: left alone, one workgroup runs 5 % ahead of the other and
-        // the CU is half empty at the end.  Swapping the priority every step keeps them level.
-        if ((((int)blockIdx.x >> 8) ^ it) & 1) { __builtin_amdgcn_s_setprio(1); } else { __builtin_amdgcn_s_setprio(0); }
-#endif
-#endif
+        r512f_draw(drawn, cnt_addr);                       // the step after this one: asked for now, needed further down
+        if constexpr (RING) {
+            // The span of this step was asked for in the middle of the last one.  Memory operations complete in
+            // issue order: behind its NV loads lie that step's row stores, so waiting until that many are
+            // outstanding leaves the stores in flight.  (First step: nothing lies behind the span.)
+            constexpr int K16 = 1028 / VEC / 64 + 1;
+            if (first_step) { r512f_wait_vm<0>(); }
+            else if (a.all16) { r512f_wait_vm<K16>(); }
+            else { r512f_wait_vm<17>(); }
+            first_step = false;
+            wave_sync();
+            R512F_STAMP(7);
+        }
         // ---- pass 1: lane (frame f, column n2 = j): 16-point FFT over the rows n1 ----
         C zz[16];
-#if R512F_ABLATE != 1
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
             if (n1 < NR) {
@@ -342,16 +415,23 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
                 }
             }
         }
-#if R512F_ABLATE != 3
         dft16c<T, NR>(zz);
-#endif
         const T *nxrow = xrow;
         if constexpr (TBL) {
             if (more) { nxrow = tbl_xrow(tvn); load_span(nxb, __builtin_amdgcn_readfirstlane(tvn)); }
         }
         R512F_STAMP(0);
         wave_sync();                                       // all lanes have read the span: the tile may overwrite it
-#if R512F_ABLATE != 4
+        if constexpr (RING) {
+            // ... and the slot takes the next step's span.  The reads of pass 1 must have RETURNED before the
+            // first load into the slot is issued: the compiler is free to sink the arithmetic that consumes them (and
+            // with it its own wait) below the assembly statements, and a read that is still queued when the first
+            // 1 KiB of the new span lands returns the new span's samples (seen as one wrong frame in a million).
+            // r512f_drawn waits for every LDS operation of the wave.  Past the end of the workgroup's share the
+            // current span is fetched again: the number of loads per step stays fixed.
+            advance();
+            load_span(more ? nxb : xb, a.ss0 + (more ? nw : w) * a.stp);
+        }
         {
             T2 *exf = ex + f * R512_EXF + j;
 #pragma unroll
@@ -374,13 +454,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
 #pragma unroll
             for (int n2 = 0; n2 < 16; ++n2) { const T2 t = exf[n2]; zz[n2] = C{t.x, t.y}; }
         }
-#else
-#pragma unroll
-        for (int k1 = 1; k1 < 16; ++k1) { zz[k1] = cx_mul<T>(zz[k1], twd[k1]); }
-#endif
-#if R512F_ABLATE != 3
         dft16c<T, 16>(zz);
-#endif
         R512F_STAMP(2);
 
         // ---- real-FFT split fused with power, in registers.  The lane holds Z[j + 16 k2] (halved);
@@ -422,7 +496,6 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
         }
         wave_sync();
         R512F_STAMP(3);
-#endif
 
         // ---- store the rows of the step: 1028 consecutive values of Y (fewer at the end of a signal:
         // the index is clamped, so the surplus lanes rewrite the last value with itself and the number
@@ -430,7 +503,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
         {
             T *yblk = yb + (unsigned)(w * F);
 #if R512F_ST4
-            if (a.W - w >= 4 && (reinterpret_cast<uintptr_t>(yblk) & 15) == 0) {
+            if (RING ? a.all16 != 0 : (a.W - w >= 4 && (reinterpret_cast<uintptr_t>(yblk) & 15) == 0)) {
                 // 1028 values = 257 16-byte vectors (float) / 514 (double): whole-vector wave stores
                 constexpr int NVEC = 1028 / VEC, FULLI = NVEC / 64;
 #pragma unroll
@@ -458,13 +531,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
                 for (int i = 0; i < 17; ++i) {
                     // the 17th instruction carries the last 4 values; its other lanes repeat value 1027
                     const int idx = (i < 16) ? lane + 64 * i : 1024 + (lane & 3);
-#if R512F_ABLATE == 2
-                    const T v = xs[idx];
-                    if (a.N == -12345) { yblk[idx] = v; }
-                    asm volatile("" :: "v"(v));
-#else
                     R512F_ST(yblk + idx, xs[idx]);
-#endif
                 }
             } else {
                 const int last = (a.W - w) * F - 1;
@@ -477,22 +544,31 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? R512F_MINWAVES_F32 : 2)) voi
         }
         R512F_STAMP(4);
         if (!more) { break; }
-        wave_sync();                                       // tile reads are done before the next span lands
+        wave_sync();                                       // tile reads are done before the next step writes it
 
-        // ---- commit the span that was in flight, step forward, start the next fetch ----
+        if constexpr (RING) {
+            sid = nsid; w = nw; xb = nxb; yb = nyb;
+        } else {
+            // ---- commit the span that was in flight, step forward, start the next fetch ----
 #pragma unroll
-        for (int q = 0; q < NV; ++q) { reinterpret_cast<TV *>(xs)[q * 64 + lane] = pre[q]; }
-        wave_sync();
-        R512F_STAMP(5);
-        sid = nsid; w = nw; xb = nxb; yb = nyb;
-        advance();
-        if constexpr (TBL) { xrow = nxrow; if (more) { tvn = tbl_fetch(nw); } }
-        else { if (more) { load_span(nxb, nw * a.stp + a.ss0); } }
-        R512F_STAMP(6);
+            for (int q = 0; q < NV; ++q) { reinterpret_cast<TV *>(xs)[q * 64 + lane] = pre[q]; }
+            wave_sync();
+            R512F_STAMP(5);
+            sid = nsid; w = nw; xb = nxb; yb = nyb;
+            advance();
+            if constexpr (TBL) { xrow = nxrow; if (more) { tvn = tbl_fetch(nw); } }
+            else { if (more) { load_span(nxb, nw * a.stp + a.ss0); } }
+            R512F_STAMP(6);
+        }
     }
+    // no LDS-DMA load may land, and no draw return, after the wave has ended (the LDS would belong to another
+    // workgroup by then)
+    if constexpr (RING) { r512f_wait_vm<0>(); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    (void)dummy;
 #if R512F_STAMPS
     if (lane == 0) {
-        const int gw = blockIdx.x * 4 + wv;
+        const int gw = blockIdx.x * NWV + wv;
         if (gw < 8192) { for (int i = 0; i < 8; ++i) { g_r512f_stamps[gw * 8 + i] = st_acc[i]; } }
     }
 #endif
@@ -515,17 +591,17 @@ bool r512_fast_supported(const FrameDesc &d)
            d.rd_shift >= 0 && d.rd_shift < (1ll << 30);
 }
 
-template <typename T, int NR, bool MN0, bool EPI, int WIDE, bool TBL = false>
+template <typename T, int NR, bool MN0, bool EPI, int WIDE, bool TBL, bool RING>
 static hipError_t launch_fast_inst(T *Y, const T *X, const T *win, const T *tw, const R512FastArgs &a, hipStream_t s)
 {
-    const size_t lds = (4 * (size_t)R512F_WAVE_ELEMS + 512 + 512) * sizeof(T);
+    constexpr int SPAN = WIDE == 2 ? 2048 : WIDE ? 1280 : 1024;
+    const size_t lds = (R512F_WAVES * ((size_t)R512F_WAVE_ELEMS + (RING ? SPAN : 0)) + 512 + 512) * sizeof(T) + 1024 + 16;
     static LdsGrant grant;
-    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r512_fast_kernel<T, NR, MN0, EPI, WIDE, TBL>), lds, grant); e != hipSuccess) { return e; }
-    static const int wgs_per_cu = [] { const char *e = getenv("DSP_R512F_WGS_PER_CU"); return e ? atoi(e) : 2; }();
-    long long grid = ((long long)a.steps + 3) / 4;
-    if (grid > 256ll * wgs_per_cu) { grid = 256ll * wgs_per_cu; }
+    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r512_fast_kernel<T, NR, MN0, EPI, WIDE, TBL, RING>), lds, grant); e != hipSuccess) { return e; }
+    long long grid = ((long long)a.steps + R512F_WAVES - 1) / R512F_WAVES;
+    if (grid > 256) { grid = 256; }                     // one 8-wave workgroup per CU
     grid = (grid + 7) & ~7ll;                           // whole groups of 8 workgroups (one per XCD)
-    hipLaunchKernelGGL((stft_r512_fast_kernel<T, NR, MN0, EPI, WIDE, TBL>), dim3((unsigned)grid), dim3(256), lds, s, Y, X, win, tw, a);
+    hipLaunchKernelGGL((stft_r512_fast_kernel<T, NR, MN0, EPI, WIDE, TBL, RING>), dim3((unsigned)grid), dim3(64 * R512F_WAVES), lds, s, Y, X, win, tw, a);
     return hipGetLastError();
 }
 
@@ -539,14 +615,21 @@ hipError_t launch_stft_r512_fast(T *Y, const T *X, const T *win, const T *tw, co
     a.steps = d.B * a.sps;
     a.tbl = d.tbl;
     if (d.tbl) { a.stp = d.tbl_reach; a.ss0 = 0; a.rd_shift = 0; }
+    a.all16 = (d.W % 4 == 0) && (reinterpret_cast<uintptr_t>(Y) % 16 == 0);
     const bool epi = d.epi.any();
+    // float, equally spaced frames: spans by LDS-DMA (the double kernel's exchange tiles leave no LDS for span slots)
+    constexpr bool RING = sizeof(T) == 4 && R512F_RING_F32;
     const bool wide = 3 * d.stp + 512 > 1024 || (d.stp & 1);   // spans of more than 1024 samples (20 staged elements per lane), odd hops
     const bool nr13 = d.L > 384 && d.L <= 416 && !wide;
-#define DSP_R512F(NR_, MN0_, EPI_) launch_fast_inst<T, NR_, MN0_, EPI_, 0>(Y, X, win, tw, a, s)
-#define DSP_R512W(MN0_, EPI_) launch_fast_inst<T, 16, MN0_, EPI_, 1>(Y, X, win, tw, a, s)
-#define DSP_R512X(MN0_, EPI_) launch_fast_inst<T, 16, MN0_, EPI_, 2>(Y, X, win, tw, a, s)
-#define DSP_R512T(MN0_, EPI_) launch_fast_inst<T, 16, MN0_, EPI_, 1, true>(Y, X, win, tw, a, s)
-#define DSP_R512U(MN0_, EPI_) launch_fast_inst<T, 16, MN0_, EPI_, 2, true>(Y, X, win, tw, a, s)
+#define DSP_R512F(NR_, MN0_, EPI_) launch_fast_inst<T, NR_, MN0_, EPI_, 0, false, RING>(Y, X, win, tw, a, s)
+#define DSP_R512W(MN0_, EPI_) launch_fast_inst<T, 16, MN0_, EPI_, 1, false, RING>(Y, X, win, tw, a, s)
+#define DSP_R512X(MN0_, EPI_) launch_fast_inst<T, 16, MN0_, EPI_, 2, false, RING>(Y, X, win, tw, a, s)
+#define DSP_R512T(MN0_, EPI_) launch_fast_inst<T, 16, MN0_, EPI_, 1, true, false>(Y, X, win, tw, a, s)
+#define DSP_R512U(MN0_, EPI_) launch_fast_inst<T, 16, MN0_, EPI_, 2, true, false>(Y, X, win, tw, a, s)
+#if R512F_MINIMAL
+    if constexpr (sizeof(T) == 4) { if (nr13 && !d.mn0 && !epi && !d.tbl) { return DSP_R512F(13, false, false); } }
+    return hipErrorInvalidValue;
+#else
     if (d.tbl && d.tbl_reach + 512 > 1280) {
         if (d.mn0) { return epi ? DSP_R512U(true, true) : DSP_R512U(true, false); }
         return epi ? DSP_R512U(false, true) : DSP_R512U(false, false);
@@ -569,6 +652,7 @@ hipError_t launch_stft_r512_fast(T *Y, const T *X, const T *win, const T *tw, co
     }
     if (d.mn0) { return epi ? DSP_R512F(16, true, true) : DSP_R512F(16, true, false); }
     return epi ? DSP_R512F(16, false, true) : DSP_R512F(16, false, false);
+#endif
 #undef DSP_R512F
 #undef DSP_R512W
 #undef DSP_R512X

@@ -47,7 +47,9 @@ __device__ __forceinline__ T fetch_sample(const T *__restrict__ xb, const FrameD
         while (n < 0 || n >= d.N) { n = (n < 0) ? -n - 1 : 2 * d.N - 1 - n; }
         return xb[n];
     }
-    return (n >= 0 && n < d.N) ? xb[n - rdoff] : T(0);
+    // (n >= rdoff: span staging also asks for samples between frames that no frame uses; with a read shift
+    // those just past the start of the signal would lie before it)
+    return (n >= 0 && n < d.N && n >= rdoff) ? xb[n - rdoff] : T(0);
 }
 
 __device__ __forceinline__ void frame_origin(const FrameDesc &d, int w, long long &ss, long long &rdoff)

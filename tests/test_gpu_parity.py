@@ -532,11 +532,13 @@ def test_full_size_batch_1024_utterances(O, D):
     for b in (0, 1, 511, 1023):
         rc, Yref = O.stft(x[b].cpu().numpy(), win.cpu().numpy(), 160, 512, exact=False)
         check_spec(O, Y[b].cpu().numpy(), Yref)
-    # (2) shift by one hop moves interior frames by one row, bit for bit (same arithmetic, new place)
-    xs = torch.roll(x[:8], shifts=-160, dims=1)
+    # (2) shift by one hop moves interior frames by one row, bit for bit (same arithmetic, another wave, another
+    # place in its step): every signal of the batch, so every interior frame is checked against a second launch
+    xs = torch.roll(x, shifts=-160, dims=1)
     Ys = D.stft_dev(xs, win, 160)
     torch.cuda.synchronize()
-    assert torch.equal(Ys[:, 2:990], Y[:8, 3:991])
+    assert torch.equal(Ys[:, 2:990], Y[:, 3:991])
+    del xs, Ys
     # (3) Parseval per frame: sum_k c_k P_k = nfft * sum_l v_l^2 (c = 1 for DC and Nyquist, else 2)
     fr = x[:4, 40:].unfold(1, 400, 160)[:, :995] * win     # frame w of the output starts at 160 w - 120
     e_time = (fr.double() ** 2).sum(-1) * 512
@@ -547,6 +549,106 @@ def test_full_size_batch_1024_utterances(O, D):
     Y2 = D.stft_dev(x[:8] * 2, win, 160)
     torch.cuda.synchronize()
     assert torch.equal(Y2, Y[:8] * 4)
+    # (5) repeated launches return the same bits (which wave takes which step differs from launch to launch; a
+    # span read before it has landed, or overwritten before it was read, shows as one frame in a million): an
+    # exact, order-independent checksum of every signal, 30 launches
+    def checksum(t):
+        return t.view(torch.int32).to(torch.int64).sum(dim=(1, 2))
+    ref = checksum(Y)
+    for _ in range(30):
+        D.stft_dev(x, win, 160, out=Y)
+        torch.cuda.synchronize()
+        assert torch.equal(checksum(Y), ref)
+
+
+def test_full_size_chunks_equal_channels_alone(O, D, monkeypatch):
+    """The multi-channel launches of the long-signal configurations: 64 and 8 channels of 1 h @ 16 kHz float64
+    through stft_flt (Povey 400, hop 160.0, c0 200), 8 channels of 1 h @ 48 kHz float32 with nfft 4096 / hop 1024.
+    Every channel of the batched output equals, bit for bit, the same channel transformed alone; head and tail rows
+    of two channels against the oracle."""
+    import torch
+    # float64 stft_flt
+    N, L = 57_600_000, 400
+    W = int((N - 1 - 200) // 160)
+    win = torch.from_numpy(D.povey(L, np.float64)).cuda()
+    g = torch.Generator(device="cuda").manual_seed(2024)
+    x = torch.randn((64, N), generator=g, device="cuda", dtype=torch.float64)
+    Y = D.stft_flt_dev(x, win, W, 200.0, 160.0)
+    torch.cuda.synchronize()
+    assert tuple(Y.shape) == (64, W, 257)
+    y1 = torch.empty((1, W, 257), device="cuda", dtype=torch.float64)
+    for b in range(64):
+        D.stft_flt_dev(x[b:b + 1], win, W, 200.0, 160.0, out=y1)
+        torch.cuda.synchronize()
+        assert torch.equal(y1[0], Y[b]), b
+    Y8 = D.stft_flt_dev(x[8:16], win, W, 200.0, 160.0)
+    torch.cuda.synchronize()
+    assert torch.equal(Y8, Y[8:16])
+    wh = win.cpu().numpy()
+    for b in (0, 63):
+        xh = x[b].cpu().numpy()
+        rc, Yref = O.stft_flt(xh[:20000], wh, 100, 200.0, 160.0, intended=True)
+        check_spec(O, Y[b, :100].cpu().numpy(), Yref)
+        w0 = W - 50
+        rc, Yref = O.stft_flt(xh[w0 * 160:], wh, 50, 200.0, 160.0, intended=True)
+        check_spec(O, Y[b, w0:].cpu().numpy(), Yref)
+    del x, Y, Y8, y1
+    torch.cuda.empty_cache()
+    # float32, nfft 4096
+    N = 172_800_000
+    W = (N + 512) // 1024
+    win = torch.from_numpy(D.blackmanharris(4096)).cuda()
+    x = torch.randn((8, N), generator=g, device="cuda", dtype=torch.float32)
+    Y = D.stft_dev(x, win, 1024)
+    torch.cuda.synchronize()
+    assert tuple(Y.shape) == (8, W, 2049)
+    y1 = torch.empty((1, W, 2049), device="cuda", dtype=torch.float32)
+    for b in range(8):
+        D.stft_dev(x[b:b + 1], win, 1024, out=y1)
+        torch.cuda.synchronize()
+        assert torch.equal(y1[0], Y[b]), b
+    wh = win.cpu().numpy()
+    for b in (0, 7):
+        xh = x[b].cpu().numpy()
+        rc, Yref = O.stft(xh[:1024 * 40], wh, 1024, 4096, exact=False)
+        check_spec(O, Y[b, :30].cpu().numpy(), Yref[:30])
+    # the last 12 frames (reflection at the right edge): oracle on the tail, whose last frames are the signal's
+    xh = x[7].cpu().numpy()
+    tail = xh[-1024 * 30:]
+    rc, Yref = O.stft(tail, wh, 1024, 4096, exact=False)
+    check_spec(O, Y[7, -12:].cpu().numpy(), Yref[-12:])
+
+
+def test_4096_run_forms_on_two_streams(O, D, monkeypatch):
+    """Two 4096-point launches whose loops deal runs from counters, with different flags (different kernel
+    instantiations), in flight together on two streams, 80 pairs in a row: neither disturbs the other's counters."""
+    import torch
+    monkeypatch.setenv("DSP_R4096_MIN_RUNS", "1")
+    win = torch.from_numpy(D.blackmanharris(4096)).cuda()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    xa = torch.randn((6, 1024 * 300), generator=g, device="cuda") + 0.3
+    xb = torch.randn((5, 1024 * 260 + 77), generator=g, device="cuda") + 0.3
+    ya_ref = D.stft_dev(xa, win, 1024)
+    yb_ref = D.stft_dev(xb, win, 1024, mn0=True)
+    torch.cuda.synchronize()
+    wh = win.cpu().numpy()
+    rc, Yref = O.stft(xa[2].cpu().numpy(), wh, 1024, 4096, exact=False)
+    check_spec(O, ya_ref[2].cpu().numpy(), Yref)
+    rc, Yref = O.stft(xb[4].cpu().numpy(), wh, 1024, 4096, 0, 1, exact=False)
+    check_spec(O, yb_ref[4].cpu().numpy(), Yref)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    ya = [torch.empty_like(ya_ref) for _ in range(4)]
+    yb = [torch.empty_like(yb_ref) for _ in range(4)]
+    for it in range(80):
+        with torch.cuda.stream(sa):
+            D.stft_dev(xa, win, 1024, out=ya[it % 4])
+        with torch.cuda.stream(sb):
+            D.stft_dev(xb, win, 1024, mn0=True, out=yb[it % 4])
+        if it % 4 == 3:
+            torch.cuda.synchronize()
+            for k in range(4):
+                assert torch.equal(ya[k], ya_ref), (it, k)
+                assert torch.equal(yb[k], yb_ref), (it, k)
 
 
 def test_full_size_long_flt_double(O, D):

@@ -13,7 +13,7 @@ h = C.CDLL(os.environ['DSP_AMD_LIB'])
 rc = h.dsp_debug_read_stamps(buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.size))
 a = buf.reshape(8192, 8)[:4096].astype(np.float64)
 tot = a.sum(1)
-names = ['p1 read+fft', 'sync+exwrite+sync', 'p2 read+fft', 'sync+zwrite+sync', 'output+stores', 'sync+commit(wait loads)+sync', 'advance+issue loads', '-']
+names = ['p1 read+fft', 'sync+exwrite+sync', 'p2 read+fft', 'sync+zwrite+sync', 'output+stores', 'sync+commit(wait loads)+sync', 'advance+issue loads', 'ring form: wait for the span']
 print('rc', rc, 'mean total cycles per wave', tot.mean(), 'steps/wave', 256000 / 4096)
 for i, n in enumerate(names):
     print(f'{n:32s} {a[:, i].mean() / (256000 / 4096):9.0f} cyc/step  {100 * a[:, i].mean() / tot.mean():5.1f}%')

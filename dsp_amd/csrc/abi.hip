@@ -13,6 +13,7 @@
 #include <cstring>
 #include <list>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <tuple>
 #include <vector>
@@ -24,8 +25,9 @@ constexpr int MAX_DEV = 64;
 constexpr size_t LDS_LIMIT = 128 * 1024;     // bytes of LDS one generic workgroup may stage
 
 thread_local int tl_device = -1;             // -1: whatever device is current
-std::atomic<int> g_flt_intended{0};
-std::atomic<int> g_force_generic{0};
+// per calling thread, like the device: two threads that want different framings do not disturb each other
+thread_local int tl_flt_intended = 0;
+thread_local int tl_force_generic = 0;
 
 #define HIPCHK(fn, call)                                                                          \
     do {                                                                                          \
@@ -36,15 +38,28 @@ std::atomic<int> g_force_generic{0};
         }                                                                                         \
     } while (0)
 
-struct TblEntry {
-    std::vector<unsigned char> key;
-    int *dev = nullptr;
+// What stft_flt's framing comes to for one (type, N, L, W, c0, stp, mode): equally spaced frames, or a table of
+// frame starts in device memory.  Cached per device, so that a repeated call neither walks the W centres on the
+// host again nor allocates or copies; a table stays alive while a call that looked it up is still enqueueing
+// its launch (the shared_ptr), and is freed with hipFree, which waits for the device, once it has been dropped
+// from the cache and no call holds it.
+struct FltKey {
+    int esz, as_ref;
+    size_t N, L, W;
+    unsigned long long c0, stp;               // bit patterns
+    bool operator==(const FltKey &o) const { return esz == o.esz && as_ref == o.as_ref && N == o.N && L == o.L && W == o.W && c0 == o.c0 && stp == o.stp; }
 };
+struct FltFraming {
+    long long ss0 = 0, rd_shift = 0;
+    int stp = 1, tbl_reach = -1;
+    std::shared_ptr<int> tbl;                 // empty: equally spaced frames
+};
+constexpr size_t FLT_CACHE = 32, FLT_TABLES = 8;
 
 struct DevState {
     std::mutex mu;                            // guards everything below
     std::map<std::tuple<int, size_t, int>, void *> tw;   // (element size, nfft, full) -> table
-    std::list<TblEntry> tbls;                 // most recently used first
+    std::list<std::pair<FltKey, FltFraming>> flt;   // most recently used first
     // workspace of the host-pointer entry points (one call at a time per device)
     std::mutex ws_mu;
     void *ws[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -87,26 +102,6 @@ int get_twiddles(const char *fn, int dev, size_t nfft, int full, const T *&out)
     HIPCHK(fn, hipMemcpy(p, h.data(), 2 * cnt * sizeof(T), hipMemcpyHostToDevice));
     st.tw[key] = p;
     out = static_cast<const T *>(p);
-    return 0;
-}
-
-// device copy of a frame table, cached by content key; a table in use is never overwritten
-int get_table(const char *fn, int dev, const std::vector<unsigned char> &key, const std::vector<int> &tbl, const int *&out)
-{
-    DevState &st = g_dev[dev];
-    std::lock_guard<std::mutex> lk(st.mu);
-    for (auto it = st.tbls.begin(); it != st.tbls.end(); ++it) {
-        if (it->key == key) { st.tbls.splice(st.tbls.begin(), st.tbls, it); out = st.tbls.front().dev; return 0; }
-    }
-    if (st.tbls.size() >= 8) {
-        HIPCHK(fn, hipFree(st.tbls.back().dev));      // hipFree waits for the device: no kernel still reads it
-        st.tbls.pop_back();
-    }
-    int *p = nullptr;
-    HIPCHK(fn, hipMalloc((void **)&p, tbl.size() * sizeof(int)));
-    HIPCHK(fn, hipMemcpy(p, tbl.data(), tbl.size() * sizeof(int), hipMemcpyHostToDevice));
-    st.tbls.push_front(TblEntry{key, p});
-    out = p;
     return 0;
 }
 
@@ -161,14 +156,14 @@ template <> constexpr double type_eps<double>() { return DBL_EPSILON; }
 // start is non-negative); otherwise reads start at the frame's own start.
 template <typename T>
 int flt_desc(const char *fn, int dev, FrameDesc &d, size_t B, size_t N, size_t ldx, size_t L, size_t W, size_t nfft, T c0, T stp,
-             int mn0, int amp, int lg, int as_reference, bool check_nfft)
+             int mn0, int amp, int lg, int as_reference, bool check_nfft, std::shared_ptr<int> &hold, T stp_min = type_eps<T>())
 {
     if (W > N) { fprintf(stderr, "error in %s: W must be <= N (length X)\n", fn); return 1; }
     if (L > N) { fprintf(stderr, "error in %s: L must be <= N (length X)\n", fn); return 1; }
     if (L < 1u) { fprintf(stderr, "error in %s: L must be positive\n", fn); return 1; }
     if (N < 1u) { fprintf(stderr, "error in %s: N (length X) must be positive\n", fn); return 1; }
     if (c0 > (T)(N - 1u)) { fprintf(stderr, "error in %s: c0 (center samp of 1st frame) must be < N (length X)\n", fn); return 1; }
-    if (stp < type_eps<T>()) { fprintf(stderr, "error in %s: stp (step size) must be positive\n", fn); return 1; }
+    if (stp < stp_min) { fprintf(stderr, "error in %s: stp (step size) must be positive\n", fn); return 1; }
     if (check_nfft) {
         if (nfft < L) { fprintf(stderr, "error in %s: nfft must be >= L\n", fn); return 1; }
         if (nfft < 2u) { fprintf(stderr, "error in %s: nfft must be >= 2\n", fn); return 1; }
@@ -182,6 +177,21 @@ int flt_desc(const char *fn, int dev, FrameDesc &d, size_t B, size_t N, size_t l
     d.mn0 = mn0 != 0; d.epi = Epilogue{amp != 0, lg != 0, 0, 0.0, 0.0}; d.B = (int)B;
     d.tbl = nullptr; d.ss0 = 0; d.rd_shift = 0; d.stp = 1;
     if (W == 0) { return 0; }
+
+    FltKey key{(int)sizeof(T), as_reference != 0, N, L, W, 0ull, 0ull};
+    memcpy(&key.c0, &c0, sizeof(T));
+    memcpy(&key.stp, &stp, sizeof(T));
+    auto apply = [&](const FltFraming &f) {
+        d.ss0 = f.ss0; d.stp = f.stp; d.rd_shift = f.rd_shift; d.tbl_reach = f.tbl_reach;
+        hold = f.tbl; d.tbl = f.tbl.get();
+    };
+    DevState &st = g_dev[dev];
+    {
+        std::lock_guard<std::mutex> lk(st.mu);
+        for (auto it = st.flt.begin(); it != st.flt.end(); ++it) {
+            if (it->first == key) { st.flt.splice(st.flt.begin(), st.flt, it); apply(st.flt.front().second); return 0; }
+        }
+    }
 
     std::vector<int> tbl(2 * W);
     const int Lpre = (int)(L / 2u), Lpost = (int)L - Lpre - 1;
@@ -199,26 +209,37 @@ int flt_desc(const char *fn, int dev, FrameDesc &d, size_t B, size_t N, size_t l
     if (!as_reference || shift < 0) { shift = 0; }
     for (size_t w = 0; w < W; ++w) { tbl[2 * w + 1] = tbl[2 * w] - (tbl[2 * w] >= 0 ? (int)shift : 0); }
     const long long hop = (W >= 2) ? (long long)tbl[2] - tbl[0] : 1;
+    FltFraming f;
     if (uniform && hop >= 1 && !(shift != 0 && left_overlap)) {
-        d.ss0 = tbl[0]; d.stp = (int)hop; d.rd_shift = shift;
-        return 0;
+        f.ss0 = tbl[0]; f.stp = (int)hop; f.rd_shift = shift;
+    } else {
+        long long reach = (shift == 0) ? 0 : -1;
+        for (size_t w = 0; reach >= 0 && w + 1 < W; ++w) {
+            if (tbl[2 * (w + 1)] < tbl[2 * w]) { reach = -1; break; }
+            const size_t w3 = (w + 3 < W) ? w + 3 : W - 1;
+            reach = std::max(reach, (long long)tbl[2 * w3] - tbl[2 * w]);
+        }
+        f.tbl_reach = (reach >= 0 && reach <= 1536) ? (int)reach : -1;
+        // (first use of a framing: an allocation and a blocking copy; repeated calls find it in the cache)
+        int *p = nullptr;
+        HIPCHK(fn, hipMalloc((void **)&p, tbl.size() * sizeof(int)));
+        f.tbl = std::shared_ptr<int>(p, [](int *q) { (void)hipFree(q); });
+        HIPCHK(fn, hipMemcpy(p, tbl.data(), tbl.size() * sizeof(int), hipMemcpyHostToDevice));
     }
-    std::vector<unsigned char> key(sizeof(size_t) * 3 + 2 * sizeof(T) + 2);
-    unsigned char *k = key.data();
-    memcpy(k, &N, sizeof(size_t)); k += sizeof(size_t);
-    memcpy(k, &L, sizeof(size_t)); k += sizeof(size_t);
-    memcpy(k, &W, sizeof(size_t)); k += sizeof(size_t);
-    memcpy(k, &c0, sizeof(T)); k += sizeof(T);
-    memcpy(k, &stp, sizeof(T)); k += sizeof(T);
-    k[0] = (unsigned char)sizeof(T); k[1] = (unsigned char)(as_reference != 0);
-    long long reach = (shift == 0) ? 0 : -1;
-    for (size_t w = 0; reach >= 0 && w + 1 < W; ++w) {
-        if (tbl[2 * (w + 1)] < tbl[2 * w]) { reach = -1; break; }
-        const size_t w3 = (w + 3 < W) ? w + 3 : W - 1;
-        reach = std::max(reach, (long long)tbl[2 * w3] - tbl[2 * w]);
+    apply(f);
+    std::list<std::pair<FltKey, FltFraming>> dropped;          // freed after the lock is released
+    {
+        std::lock_guard<std::mutex> lk(st.mu);
+        st.flt.emplace_front(key, f);
+        size_t tables = 0;
+        for (auto it = st.flt.begin(); it != st.flt.end();) {
+            auto cur = it++;
+            const size_t pos = (size_t)std::distance(st.flt.begin(), cur);
+            if (cur->second.tbl && ++tables > FLT_TABLES) { dropped.splice(dropped.end(), st.flt, cur); }
+            else if (pos >= FLT_CACHE) { dropped.splice(dropped.end(), st.flt, cur); }
+        }
     }
-    d.tbl_reach = (reach >= 0 && reach <= 1536) ? (int)reach : -1;
-    return get_table(fn, dev, key, tbl, d.tbl);
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -229,9 +250,9 @@ int family_of(size_t nfft)
 {
     if (nfft < 2) { return 0; }
     if (!is_pow2(nfft)) { return 1; }
-    if (nfft == 512 && !g_force_generic.load()) { return 3; }
-    if (nfft == 4096 && sizeof(T) == 4 && !g_force_generic.load()) { return 4; }
-    if (!g_force_generic.load() && nfft <= (1u << 20)) {
+    if (nfft == 512 && !tl_force_generic) { return 3; }
+    if (nfft == 4096 && sizeof(T) == 4 && !tl_force_generic) { return 4; }
+    if (!tl_force_generic && nfft <= (1u << 20)) {
         FrameDesc probe{};
         probe.nfft = (int)nfft; probe.L = 1;
         if (wave_fft_supported<T>(probe)) { return 5; }
@@ -315,11 +336,13 @@ int stft_flt_host(const char *fn, T *Y, const T *X, const T *win, size_t N, size
     // argument checks come before any device work, as in the reference
     FrameDesc d;
     int dev = 0;
-    if (W > N || L > N || L < 1u || N < 1u || c0 > (T)(N - 1u) || stp < type_eps<T>() || nfft < L || nfft < 2u || W == 0) {
-        return flt_desc<T>(fn, 0, d, 1, N, N, L, W, nfft, c0, stp, mn0, amp, lg, !g_flt_intended.load(), true);
+    std::shared_ptr<int> hold;
+    const T stp_min = (T)FLT_EPSILON;             // both precisions: reference c/stft_flt.c:40,139
+    if (W > N || L > N || L < 1u || N < 1u || c0 > (T)(N - 1u) || stp < stp_min || nfft < L || nfft < 2u || W == 0) {
+        return flt_desc<T>(fn, 0, d, 1, N, N, L, W, nfft, c0, stp, mn0, amp, lg, !tl_flt_intended, true, hold, stp_min);
     }
     if (use_device(fn, dev)) { return 1; }
-    if (flt_desc<T>(fn, dev, d, 1, N, N, L, W, nfft, c0, stp, mn0, amp, lg, !g_flt_intended.load(), true)) { return 1; }
+    if (flt_desc<T>(fn, dev, d, 1, N, N, L, W, nfft, c0, stp, mn0, amp, lg, !tl_flt_intended, true, hold, stp_min)) { return 1; }
     return run_fused_host<T>(fn, dev, Y, X, win, d, N);
 }
 
@@ -343,13 +366,15 @@ int stft_flt_dev(const char *fn, T *Yd, const T *Xd, const T *wd, size_t B, size
 {
     FrameDesc d;
     int dev = 0;
-    if (W > N || L > N || L < 1u || N < 1u || c0 > (T)(N - 1u) || stp < type_eps<T>() || nfft < L || nfft < 2u || W == 0 || B == 0) {
-        return flt_desc<T>(fn, 0, d, B, N, ldx, L, W, nfft, c0, stp, mn0, amp, lg, !g_flt_intended.load(), true);
+    std::shared_ptr<int> hold;
+    const T stp_min = (T)FLT_EPSILON;             // both precisions: reference c/stft_flt.c:40,139
+    if (W > N || L > N || L < 1u || N < 1u || c0 > (T)(N - 1u) || stp < stp_min || nfft < L || nfft < 2u || W == 0 || B == 0) {
+        return flt_desc<T>(fn, 0, d, B, N, ldx, L, W, nfft, c0, stp, mn0, amp, lg, !tl_flt_intended, true, hold, stp_min);
     }
     if (B > 1 && ldx < N) { fprintf(stderr, "error in %s: ldx must be >= N\n", fn); return 1; }
     if (!Yd || !Xd || !wd) { fprintf(stderr, "error in %s: null device pointer\n", fn); return 1; }
     if (use_device(fn, dev)) { return 1; }
-    if (flt_desc<T>(fn, dev, d, B, N, ldx, L, W, nfft, c0, stp, mn0, amp, lg, !g_flt_intended.load(), true)) { return 1; }
+    if (flt_desc<T>(fn, dev, d, B, N, ldx, L, W, nfft, c0, stp, mn0, amp, lg, !tl_flt_intended, true, hold, stp_min)) { return 1; }
     return run_fused<T>(fn, dev, Yd, Xd, wd, d, (hipStream_t)stream);
 }
 
@@ -647,11 +672,12 @@ int frame_univar_flt_host(const char *fn, T *Y, const T *X, size_t N, size_t L, 
 {
     FrameDesc d;
     int dev = 0;
+    std::shared_ptr<int> hold;
     if (W > N || L > N || L < 1u || N < 1u || c0 > (T)(N - 1u) || stp < type_eps<T>() || W == 0) {
-        return flt_desc<T>(fn, 0, d, 1, N, N, L, W, 2, c0, stp, 0, 0, 0, 0, false);
+        return flt_desc<T>(fn, 0, d, 1, N, N, L, W, 2, c0, stp, 0, 0, 0, 0, false, hold);
     }
     if (use_device(fn, dev)) { return 1; }
-    if (flt_desc<T>(fn, dev, d, 1, N, N, L, W, 2, c0, stp, 0, 0, 0, 0, false)) { return 1; }
+    if (flt_desc<T>(fn, dev, d, 1, N, N, L, W, 2, c0, stp, 0, 0, 0, 0, false, hold)) { return 1; }
     return frames_host<T>(fn, Y, X, d, E, dev, win);
 }
 
@@ -905,8 +931,8 @@ int dsp_set_device(const int device)
     return 0;
 }
 
-int dsp_stft_flt_set_mode(const int intended) { g_flt_intended.store(intended != 0); return 0; }
-int dsp_stft_force_generic(const int on) { g_force_generic.store(on != 0); return 0; }
+int dsp_stft_flt_set_mode(const int intended) { tl_flt_intended = intended != 0; return 0; }
+int dsp_stft_force_generic(const int on) { tl_force_generic = on != 0; return 0; }
 
 int dsp_stft_kernel_family(const size_t nfft, const size_t elem_size)
 {

@@ -59,14 +59,25 @@ __device__ __forceinline__ void frame_origin(const FrameDesc &d, int w, long lon
 }
 
 // sqrt and natural log of a power value.  float: the hardware's 1-ulp v_sqrt_f32 and v_log_f32 (log2)
-// with the change of base carried in two parts, 3 instructions instead of the library's ~12 each
-// (16 values per lane and step: the library forms double the kernel's instruction count); inputs
-// below 2^-126 count as zero.  double: the library functions.
-__device__ __forceinline__ float epi_sqrt(float v) { return __builtin_amdgcn_sqrtf(v); }
+// with the change of base carried in two parts, a handful of instructions instead of the library's ~12 each
+// (16 values per lane and step: the library forms double the kernel's instruction count).  Both
+// instructions take a denormal input for zero, so values below 2^-96 are scaled by 2^64 first and the
+// result is corrected (sqrt: times 2^-32, log2: minus 64): powers of very quiet signals come out as the
+// library's sqrtf / logf give them, not as 0 / -inf.  double: the library functions.
+__device__ __forceinline__ float epi_sqrt(float v)
+{
+    const bool tiny = v < 0x1p-96f;
+    return __builtin_amdgcn_sqrtf(tiny ? v * 0x1p64f : v) * (tiny ? 0x1p-32f : 1.0f);
+}
 __device__ __forceinline__ double epi_sqrt(double v) { return sqrt(v); }
+__device__ __forceinline__ float epi_log2(float v)
+{
+    const bool tiny = v < 0x1p-96f;
+    return __builtin_amdgcn_logf(tiny ? v * 0x1p64f : v) - (tiny ? 64.0f : 0.0f);
+}
 __device__ __forceinline__ float epi_log(float v)
 {
-    const float l2 = __builtin_amdgcn_logf(v);                       // log2(v)
+    const float l2 = epi_log2(v);
     // ln 2 = hi + lo with hi the float BELOW ln 2, so that both parts have the sign of l2 and log(0) = -inf,
     // log(inf) = inf come out of the same two instructions (no inf - inf)
     return fmaf(l2, 0.6931471228599548f, l2 * 5.769998878690785e-08f);
@@ -76,25 +87,32 @@ __device__ __forceinline__ double epi_log(double v) { return log(v); }
 // instead of the library's 40 to 80, which made the fused cube-root epilogue cost two thirds of the
 // whole 512-point kernel (0.65 ms against 0.40).  cbrt: exp2(log2|v| / 3) and one Newton step (to about
 // 1 ulp).  pow: log2 v refined by one step (v 2^-l0 - 1) / ln 2, the product with p carried in two parts,
-// exp2 of the high part times 1 + ln 2 (low part): about 2 ulp.  Zero, infinities and NaN as the library.
+// exp2 of the high part times 1 + ln 2 (low part): about 2 ulp.  Zero, infinities and NaN as the library;
+// denormal arguments and results through the same scaling as above.
 __device__ __forceinline__ float epi_cbrt(float v)
 {
-    const float a = fabsf(v);
+    const float a0 = fabsf(v);
+    const bool tiny = a0 < 0x1p-96f;
+    const float a = tiny ? a0 * 0x1p96f : a0;             // cbrt(2^96) = 2^32
     const float y0 = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(a) * 0.3333333432674407958984375f);
     const float r = __builtin_amdgcn_rcpf(y0 * y0);
     const float y = fmaf(a * r, 0.3333333432674407958984375f, y0 * 0.666666686534881591796875f);
-    return copysignf((y0 == 0.0f || y0 == __builtin_inff()) ? y0 : y, v);
+    return copysignf(((y0 == 0.0f || y0 == __builtin_inff()) ? y0 : y) * (tiny ? 0x1p-32f : 1.0f), v);
 }
 __device__ __forceinline__ double epi_cbrt(double v) { return cbrt(v); }
 __device__ __forceinline__ float epi_pow(float v, float p)
 {
-    const float l0 = __builtin_amdgcn_logf(v);                        // NaN for v < 0, as pow with a fractional p
-    const float r = v * __builtin_amdgcn_exp2f(-l0);                  // 1 + eps
+    const bool tiny = v < 0x1p-96f;
+    const float vs = tiny ? v * 0x1p64f : v;
+    const float ls = __builtin_amdgcn_logf(vs);                       // NaN for v < 0, as pow with a fractional p
+    const float r = vs * __builtin_amdgcn_exp2f(-ls);                 // 1 + eps
     const float corr = (r - 1.0f) * 1.44269502162933349609375f;       // log2(1 + eps)
+    const float l0 = ls - (tiny ? 64.0f : 0.0f);
     const float eh = p * l0;
     const float el = fmaf(p, l0, -eh) + p * corr;
-    const float yh = __builtin_amdgcn_exp2f(eh);
-    const float y = fmaf(yh * 0.693147182464599609375f, el, yh);
+    const bool low = eh < -100.0f;                                    // the result is near or below 2^-126: exp2 of a shifted exponent
+    const float yh = __builtin_amdgcn_exp2f(low ? eh + 64.0f : eh);
+    const float y = fmaf(yh * 0.693147182464599609375f, el, yh) * (low ? 0x1p-64f : 1.0f);
     return (v == 0.0f || fabsf(l0) == __builtin_inff()) ? ((v == 0.0f) ? 0.0f : v) : y;
 }
 __device__ __forceinline__ double epi_pow(double v, double p) { return pow(v, p); }

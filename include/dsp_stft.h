@@ -158,7 +158,9 @@ int convert_freqs_d (double *frqs, const size_t F, const char in_scale[], const 
 /* Number of frames of stft_s/_d (reference formula, c/stft.c:40); 0 when the arguments are invalid. */
 size_t dsp_stft_num_frames (const size_t N, const size_t L, const size_t stp, const int snip_edges);
 
-/* Selects the HIP device used by the calling thread's later calls (default: the current device). */
+/* Selects the HIP device used by the calling thread's later calls (default: the current device).  This,
+ * dsp_stft_flt_set_mode and dsp_stft_force_generic are settings of the CALLING THREAD: threads that want
+ * different devices or framings do not disturb each other, and a new thread starts with the defaults. */
 int dsp_set_device (const int device);
 
 /* stft_flt framing: 0 (default) = what the reference's code computes: once frames stop overlapping

@@ -515,6 +515,48 @@ def test_log_of_silence_is_minus_inf(D):
     assert np.all(np.isneginf(Y))
 
 
+@pytest.mark.parametrize("nfft,L,stp", [(512, 400, 160), (4096, 4096, 1024), (256, 200, 80)])
+def test_very_quiet_signal_float32(O, D, nfft, L, stp):
+    """A float32 signal so quiet that its power values are denormal (below 2^-126): -a and -l must give what
+    sqrtf / logf give for them (the reference calls those, c/stft.c:86-95), not 0 / -inf, and so must the power
+    compression of pow_compress (c/pow_compress.c:30-46) on such values."""
+    dt = np.float32
+    x = (signal(31, 60000, dt) * dt(3e-21 * (400.0 / L) ** 0.5)).astype(dt)
+    win = D.hann(L, dt)
+    for (amp, lg) in [(0, 0), (1, 0), (0, 1), (1, 1)]:
+        rc, Yref = O.stft(x, win, stp, nfft, 0, 0, amp, lg)
+        assert rc == 0
+        P = Yref if not lg else np.exp(Yref.astype(np.float64))
+        assert 0 < np.median(P) < (1e-19 if amp else 3e-39)              # the case is what it claims to be
+        Y = D.stft(x, win, stp, False, False, bool(amp), bool(lg), nfft=nfft)
+        assert np.all(np.isfinite(Y) == np.isfinite(Yref)) and not np.any(np.isnan(Y))
+        # compared as power values (a denormal power carries only a few bits, so its square root or logarithm
+        # differs between two correct implementations by far more than the path's bound): the bound of the path
+        # plus four steps of the denormal grid, 2^-149
+        def as_power(A):
+            A = A.astype(np.float64)
+            A = np.exp(A) if lg else A
+            return A * A if amp else A
+        Pg, Pr = as_power(Y), as_power(Yref)
+        fmax = Pr.max(axis=1, keepdims=True)
+        # (a logarithm near -90 is itself only given to 8e-6: four steps of its float32 grid, as a factor on the power)
+        slack = Pr * (4 * np.spacing(np.abs(Yref)).astype(np.float64) * (2 if amp else 1)) if lg else 0.0
+        assert np.all(np.abs(Pg - Pr) <= 1e-5 * fmax + 5.7e-45 + slack), (amp, lg)
+        assert np.count_nonzero(Pg) > 0.99 * Pg.size                     # not flushed to zero
+    rc, Ypow = O.stft(x, win, stp, nfft)
+    for p in (0.0, 0.5, 1.0 / 3.0, 0.3, 0.97):
+        got = D.pow_compress(Ypow, p, 0.0)
+        with np.errstate(divide="ignore"):
+            want = (np.log(Ypow.astype(np.float64)) if p == 0.0 else np.power(Ypow.astype(np.float64), p))
+        ok = np.isfinite(want) & (Ypow > 1e-42)                       # (a few denormal bits: nothing to compare below)
+        if p == 0.0:
+            assert np.max(np.abs(got[ok] - want[ok])) < 2e-5, p
+        else:
+            # (relative bound of the path plus two steps of the denormal grid, 2^-149, on which such results lie)
+            assert np.all(np.abs(got[ok] - want[ok]) <= 2e-5 * np.abs(want[ok]) + 2.9e-45), p
+        assert np.all(got[Ypow == 0] == (-np.inf if p == 0.0 else 0.0))
+
+
 # ---------------------------------------------------------------------------------------------------
 # full benchmark sizes: size-independent properties + sampled oracle checks
 # ---------------------------------------------------------------------------------------------------
@@ -649,6 +691,59 @@ def test_4096_run_forms_on_two_streams(O, D, monkeypatch):
             for k in range(4):
                 assert torch.equal(ya[k], ya_ref), (it, k)
                 assert torch.equal(yb[k], yb_ref), (it, k)
+
+
+def test_stft_flt_dev_repeated_calls_only_enqueue(O, D):
+    """200 device-resident stft_flt calls with a non-integral hop (frame starts from a table) alternating over two
+    streams, nothing synchronised in between: after the first call of a framing the entry point neither walks the
+    centres on the host nor allocates or copies (the host time of a repeated call is measured and bounded), and
+    every output equals the oracle's."""
+    import ctypes as C
+    import time
+    import torch
+    from dsp_amd._lib import lib
+    dt = np.float32
+    N, L, W, c0, stp = 400_000, 400, 2990, 133.0, 133.37
+    x = torch.from_numpy(np.stack([signal(70 + b, N, dt) for b in range(3)])).cuda()
+    win = torch.from_numpy(D.povey(L, dt)).cuda()
+    D.set_flt_mode(True)
+    try:
+        ref = D.stft_flt_dev(x, win, W, c0, stp)            # first use of this framing: builds and uploads the table
+        torch.cuda.synchronize()
+        for b in range(3):
+            rc, Yref = O.stft_flt(x[b].cpu().numpy(), win.cpu().numpy(), W, c0, stp, intended=True)
+            check_spec(O, ref[b].cpu().numpy(), Yref)
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        outs = [torch.empty_like(ref) for _ in range(8)]
+        fn = lib().dsp_stft_flt_batch_dev_s
+        t_host = 0.0
+        for it in range(200):
+            s = streams[it % 2]
+            y = outs[it % 8]
+            t0 = time.perf_counter()
+            rc = fn(C.c_void_p(y.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(win.data_ptr()), 3, N, N, L, W, 512,
+                    c0, stp, 0, 0, 0, C.c_void_p(s.cuda_stream))
+            t_host += time.perf_counter() - t0
+            assert rc == 0
+            if it % 8 == 7:
+                torch.cuda.synchronize()
+                for k in range(8):
+                    assert torch.equal(outs[k], ref), (it, k)
+                    outs[k].zero_()
+        print(f"host time per repeated dsp_stft_flt_batch_dev_s call, alternating streams: {t_host / 200 * 1e6:.1f} us")
+        # the entry point's own host time: one stream (the runtime's change of stream costs more than the call)
+        s0 = C.c_void_p(streams[0].cuda_stream)
+        y = outs[0]
+        t0 = time.perf_counter()
+        for it in range(200):
+            fn(C.c_void_p(y.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(win.data_ptr()), 3, N, N, L, W, 512, c0, stp, 0, 0, 0, s0)
+        per_call_us = (time.perf_counter() - t0) / 200 * 1e6
+        torch.cuda.synchronize()
+        assert torch.equal(y, ref)
+        print(f"host time per repeated dsp_stft_flt_batch_dev_s call, one stream: {per_call_us:.1f} us")
+        assert per_call_us < 20, per_call_us        # (W = 2990 centres on the host alone would be ~10 us, an upload ~50)
+    finally:
+        D.set_flt_mode(False)
 
 
 def test_full_size_long_flt_double(O, D):

@@ -3,22 +3,28 @@
 
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
-One step = one pass of the fused STFT kernel over one resident batch of synthetic signals (one
-kernel launch).  Default workload: 1024 utterances x 10 s @ 16 kHz float32, Hann window 400, hop 160,
-nfft 512 (1 024 000 frames per GPU per step); with N GPUs every rank holds its own 1024 utterances
-(weak scaling, signals sharded by rank, no collective on the data path).  Inputs and outputs are
-resident in HBM; host<->device copies are outside the timed region.
+One step = one pass of the fused STFT kernel over one resident batch of synthetic signals (one kernel
+launch).  N = 1: 1024 utterances x 10 s @ 16 kHz float32, Hann window 400, hop 160, nfft 512 (1 024 000
+frames per step).  N > 1: every rank holds 8192 such utterances (at N = 8 the 65 536 utterances of the
+sharded configuration), signals sharded by rank, no collective on the data path; the gather of the
+spectrogram shards to rank 0 (RCCL) is timed separately, alone and overlapped with the computation in
+pieces, and is never part of `value`.  Inputs and outputs are resident in HBM; host<->device copies are
+outside the timed region.
 
-Prints ONE JSON line on rank 0.  `roofline.achieved` = algorithmic bytes per launch (every input
-sample read once + window + every output value written once) / mean launch duration from HIP events
-recorded on the launch stream.  `cpu_baseline` = the CPU oracle's T-precision build (a port of the
-reference loop, one thread) timed on a stated sample of the same workload.
+Prints ONE JSON line on rank 0.  `roofline.achieved` = algorithmic bytes per launch (every input sample
+read once + window + every output value written once) / mean launch duration from HIP events recorded on
+the launch stream.  `cpu_baseline` = the CPU oracle's T-precision build (a port of the reference loop; on
+FFTW itself where the host has libfftw3) timed on a stated sample of the same workload, one thread (the
+reference is single-threaded) and on all the cores this process may use.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
+import tempfile
+import threading
 import time
 
 import numpy as np
@@ -27,49 +33,154 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak
+FP32_VALU_PEAK_TFLOPS = 157.3   # MI355X FP32 vector peak
 
 WORKLOADS = {
     # name: (dtype, B per GPU, N, window, L, hop, nfft, kind)
     "utt1024x10s_f32_hann400_hop160_nfft512": ("float32", 1024, 160000, "hann", 400, 160, 512, "stft"),
+    "utt8192x10s_f32_hann400_hop160_nfft512": ("float32", 8192, 160000, "hann", 400, 160, 512, "stft"),
     "utt1x10s_f32_hann400_hop160_nfft512": ("float32", 1, 160000, "hann", 400, 160, 512, "stft"),
     "flt_f64_8ch_x_1h16k_povey400_hop160_nfft512": ("float64", 8, 57600000, "povey", 400, 160, 512, "flt"),
     "longwin_f32_8ch_x_1h48k_bh4096_hop1024_nfft4096": ("float32", 8, 172800000, "blackmanharris", 4096, 1024, 4096, "stft"),
 }
-DEFAULT = "utt1024x10s_f32_hann400_hop160_nfft512"
+DEFAULT_1GPU = "utt1024x10s_f32_hann400_hop160_nfft512"
+DEFAULT_NGPU = "utt8192x10s_f32_hann400_hop160_nfft512"
 
 
-def cpu_baseline(x_host, win, stp, nfft, kind, W, budget_s=12.0):
-    """Times the oracle's T-precision build (oracle/liborc_fast.so, -O3 -ffast-math, one thread) on as
-    many whole signals of the batch as fit the budget; returns (frames/s, description)."""
-    path = os.path.join(ROOT, "oracle", "liborc_fast.so")
-    lib = C.CDLL(path)
+def host_cores():
+    """Cores this process may run on (the box's share, not the machine's count), capped by OMP_NUM_THREADS."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    cap = os.environ.get("OMP_NUM_THREADS")
+    if cap and cap.isdigit() and int(cap) > 0:
+        n = min(n, int(cap))
+    return max(1, n)
+
+
+def find_fftw(lib, sfx):
+    """Hands FFTW's planner to the oracle if libfftw3(f).so.3 can be loaded on this host; returns a label."""
+    name = "libfftw3f.so.3" if sfx == "s" else "libfftw3.so.3"
+    pre = "fftwf_" if sfx == "s" else "fftw_"
+    try:
+        f = C.CDLL(name)
+        ptr = lambda n: C.cast(getattr(f, pre + n), C.c_void_p)  # noqa: E731
+        getattr(lib, f"orc_set_fftw_{sfx}")(ptr("plan_r2r_1d"), ptr("execute"), ptr("destroy_plan"))
+        return True, f"{name} found: reference loop on FFTW (r2r R2HC plan, FFTW_ESTIMATE, one plan per call)"
+    except (OSError, AttributeError) as e:
+        return False, f"{name} not loadable on this host ({type(e).__name__}): in-repo port of the reference loop"
+
+
+def cpu_baseline(x_host, win, stp, nfft, kind, W, budget_s=10.0):
+    """Times the oracle's T-precision build (oracle/liborc_fast.so, -O3 -ffast-math) on whole signals of the
+    sample for `budget_s` seconds: one thread, then one thread per core.  Returns the cpu_baseline object."""
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "liborc_fast.so"))
     sfx = "s" if x_host.dtype == np.float32 else "d"
     ct = C.c_float if sfx == "s" else C.c_double
     N, L = x_host.shape[1], win.size
     F = nfft // 2 + 1
-    Y = np.empty((W, F), dtype=x_host.dtype)
     vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
     sz = C.c_size_t
-
-    def one(b):
-        if kind == "flt":
-            f = getattr(lib, f"orc_stft_flt_{sfx}")
-            f.restype = C.c_int
-            return f(vp(Y), vp(x_host[b]), vp(win), sz(N), sz(L), sz(W), sz(nfft), ct(L // 2), ct(stp), 0, 0, 0, 1, 1)
-        f = getattr(lib, f"orc_stft_{sfx}")
-        f.restype = C.c_int
-        return f(vp(Y), vp(x_host[b]), vp(win), sz(N), sz(L), sz(nfft), sz(stp), 0, 0, 0, 0, 1)
-
-    assert one(0) == 0          # warm-up (twiddle table, page faults)
-    t0 = time.perf_counter()
-    done = 0
+    have_fftw, fftw_note = find_fftw(lib, sfx)
+    mode = 2 if have_fftw else 1
+    f_flt, f_stft = getattr(lib, f"orc_stft_flt_{sfx}"), getattr(lib, f"orc_stft_{sfx}")
+    f_flt.restype = f_stft.restype = C.c_int
     nb = x_host.shape[0]
-    while time.perf_counter() - t0 < budget_s:      # whole signals, cycling through the sample
-        assert one(done % nb) == 0
-        done += 1
-    dt = time.perf_counter() - t0
-    return done * W / dt, (f"{done} signal transforms cycling over {nb} signals of the batch "
-                           f"({done * W} frames, {dt:.1f} s, one thread)")
+
+    def one(Y, b):
+        if kind == "flt":
+            return f_flt(vp(Y), vp(x_host[b]), vp(win), sz(N), sz(L), sz(W), sz(nfft), ct(L // 2), ct(stp), 0, 0, 0, 1, mode)
+        return f_stft(vp(Y), vp(x_host[b]), vp(win), sz(N), sz(L), sz(nfft), sz(stp), 0, 0, 0, 0, mode)
+
+    def leg(threads):
+        done = [0] * threads
+        t0 = time.perf_counter()
+
+        def work(i):
+            Y = np.empty((W, F), dtype=x_host.dtype)
+            assert one(Y, i % nb) == 0                  # warm-up (twiddle table, page faults)
+            k = i
+            while time.perf_counter() - t0 < budget_s:  # whole signals, cycling through the sample
+                assert one(Y, k % nb) == 0              # (the foreign call releases the interpreter lock)
+                k += threads
+                done[i] += 1
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        dt = time.perf_counter() - t0
+        return sum(done) * W / dt, sum(done), dt
+
+    cores = host_cores()
+    v1, n1, t1 = leg(1)
+    vall, nall, tall = leg(cores) if cores > 1 else (v1, n1, t1)
+    return {
+        "value": v1, "unit": "frames/s", "cores": 1, "kind": "port",
+        "sample": (f"{n1} signal transforms cycling over {nb} signal(s) of the batch, {x_host.shape[1]} samples each "
+                   f"({n1 * W} frames, {t1:.1f} s, one thread: the reference is single-threaded, c/fft.fftw.r2hc.c:8)"),
+        "all_cores": {"value": vall, "unit": "frames/s", "cores": cores,
+                      "sample": f"{nall} signal transforms, one signal per thread at a time ({nall * W} frames, {tall:.1f} s)"},
+        "host": {"cores_usable": cores, "cpu_count": os.cpu_count(), "fft": fftw_note},
+    }
+
+
+def config1_extras(dsp_amd, x, win_h, stp, nfft):
+    """One utterance through the drop-in boundary: the host-pointer stft_s (copies included) and the stft
+    command-line tool as a process (HIP set-up, code object, file I/O included), beside the device-resident call."""
+    import torch
+    xh = x[0].cpu().numpy()
+    for _ in range(20):
+        dsp_amd.stft(xh, win_h, stp)
+    t0 = time.perf_counter()
+    for _ in range(200):
+        dsp_amd.stft(xh, win_h, stp)
+    host_us = (time.perf_counter() - t0) / 200 * 1e6
+    win = torch.from_numpy(win_h).to(x.device)
+    y = dsp_amd.stft_dev(x, win, stp)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(200):
+        dsp_amd.stft_dev(x, win, stp, out=y)
+        torch.cuda.synchronize()
+    dev_us = (time.perf_counter() - t0) / 200 * 1e6
+    out = {"stft_s_host_pointers_us_per_call": host_us, "stft_batch_dev_plus_sync_us_per_call": dev_us}
+    tool = os.path.join(ROOT, "bin", "stft")
+    if os.path.exists(tool):
+        with tempfile.TemporaryDirectory() as d:
+            np.save(os.path.join(d, "x.npy"), xh)
+            np.save(os.path.join(d, "w.npy"), win_h)
+            walls = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                rc = subprocess.run([tool, "-s", str(stp), "-o", os.path.join(d, "y.npy"), os.path.join(d, "x.npy"), os.path.join(d, "w.npy")]).returncode
+                walls.append((time.perf_counter() - t0) * 1e3)
+                if rc != 0:
+                    break
+            if rc == 0:
+                out["stft_tool_process_wall_ms"] = {"min": min(walls), "median": float(np.median(walls)), "runs": len(walls)}
+    return out
+
+
+def gather_leg(x, win, B, world, rank, compute, chunks, sync, **kw):
+    """The gather of the shards to rank 0, as dsp_amd.dist does it: (i) alone, after the shard is computed;
+    (ii) computation and gather pipelined in `chunks` pieces.  Returns (timings in ms, Y_full on rank 0)."""
+    from dsp_amd.dist import stft_sharded
+    res = {}
+    sync()
+    t0 = time.perf_counter()
+    y, full = stft_sharded(x, win, world * B, rank, world, gather="root", compute=compute, chunks=1, **kw)
+    sync()
+    res["compute_then_gather_ms"] = (time.perf_counter() - t0) * 1e3
+    del full
+    sync()
+    t0 = time.perf_counter()
+    y, full = stft_sharded(x, win, world * B, rank, world, gather="root", compute=compute, chunks=chunks, **kw)
+    sync()
+    res["pipelined_ms"] = (time.perf_counter() - t0) * 1e3
+    res["chunks"] = chunks
+    return res, full
 
 
 def main():
@@ -77,10 +188,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default=DEFAULT, choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--ramp-ms", type=float, default=300.0, help="untimed device work before the warmup steps (clock ramp); 0 disables")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather", action="store_true", help="also time one RCCL all-gather of the output shards")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the (separately timed) gather of the shards to rank 0")
+    ap.add_argument("--gather-chunks", type=int, default=8)
     ap.add_argument("--generic", action="store_true", help="force the generic kernel family (A/B)")
     args = ap.parse_args()
 
@@ -94,12 +206,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # DSP_BENCH_REHEARSAL=1: all ranks on GPU 0 with the gloo backend, to rehearse the N > 1 path on a one-GPU box
+    rehearsal = os.environ.get("DSP_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    workload = args.workload or (DEFAULT_1GPU if world == 1 else DEFAULT_NGPU)
 
-    dtname, B, N, wname, L, stp, nfft, kind = WORKLOADS[args.workload]
+    dtname, B, N, wname, L, stp, nfft, kind = WORKLOADS[workload]
     tdt = torch.float32 if dtname == "float32" else torch.float64
     ndt = np.float32 if dtname == "float32" else np.float64
     esz = np.dtype(ndt).itemsize
@@ -154,47 +274,59 @@ def main():
         elapsed = float(t.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
-    gather_ms = None
-    if args.gather and world > 1:
-        full = torch.empty((world * B, W, F), dtype=tdt, device=dev)
-        dist.all_gather_into_tensor(full, y)
-        sync_all()
-        t1 = time.perf_counter()
-        dist.all_gather_into_tensor(full, y)
-        sync_all()
-        gather_ms = (time.perf_counter() - t1) * 1e3
-        del full
+    gather = None
+    if world > 1 and not args.no_gather and kind == "stft":
+        # separately timed, never part of `value`; a failure here must not lose the throughput line
+        try:
+            del y
+            res, full = gather_leg(x, win, B, world, rank, dsp_amd.stft_dev, args.gather_chunks, sync_all, stp=stp)
+            tm = torch.tensor([res["compute_then_gather_ms"], res["pipelined_ms"]], dtype=torch.float64, device=dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            gather = {"to": "rank 0", "backend": dist.get_backend(), "rccl_world_size": dist.get_world_size(),
+                      "bytes_per_rank": B * W * F * esz, "compute_then_gather_ms": float(tm[0].item()),
+                      "pipelined_ms": float(tm[1].item()), "chunks": res["chunks"]}
+            del full
+        except Exception as e:  # noqa: BLE001
+            gather = {"error": f"{type(e).__name__}: {e}"}
 
     frames_per_step = world * B * W
     value = frames_per_step * args.steps / elapsed
     alg_bytes = B * N * esz + L * esz + B * W * F * esz           # per launch (one GPU)
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    tflops = 5 * nfft * np.log2(nfft) * B * W / (kern_ms * 1e-3) / 1e12
 
+    # HBM bytes per launch from the PMC counters: collected by separate rocprofv3 passes (tools/experiments/prof_round.sh),
+    # not in this run
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get(args.workload)
+        traffic = json.load(open(tpath)).get(workload)
 
     out = {
         "metric": "stft_frames_per_sec", "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32" if esz == 4 else "f64", "data": "synthetic",
-        "config": {"workload": args.workload, "signals_per_gpu": B, "samples_per_signal": N, "window": wname, "L": L,
+        "config": {"workload": workload, "signals_per_gpu": B, "samples_per_signal": N, "window": wname, "L": L,
                    "hop": stp, "nfft": nfft, "frames_per_signal": W, "entry_point": "dsp_stft_flt_batch_dev" if kind == "flt" else "dsp_stft_batch_dev",
                    "kernel_family": "generic" if args.generic else {1: "direct", 2: "pow2", 3: "r512", 4: "r4096", 5: "wave"}[dsp_amd.kernel_family(nfft, ndt)],
                    "sharding": f"{world} ranks x {B} signals, no data-path collective", "device_ramp_ms": args.ramp_ms},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms,
-                     "nominal_tflops_5NlogN": 5 * nfft * np.log2(nfft) * B * W / (kern_ms * 1e-3) / 1e12},
+                     "traffic": traffic, "traffic_source": "profiles/traffic.json (separate rocprofv3 --pmc passes)" if traffic else None,
+                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms, "nominal_tflops_5NlogN": tflops},
     }
-    if gather_ms is not None:
-        out["gather_ms"] = gather_ms
+    if esz == 4:
+        # the other bound of this path: float32 vector issue, on the nominal 5 N log2 N flops (nfft 4096 sits on the ridge)
+        out["roofline_valu"] = {"bound": "fp32_valu", "achieved": tflops, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": tflops / FP32_VALU_PEAK_TFLOPS}
+    if gather is not None:
+        out["gather"] = gather
+    if rank == 0 and world == 1 and B == 1:
+        out["one_utterance"] = config1_extras(dsp_amd, x, win_h, stp, nfft)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         nb = min(B, 256) if N <= 1_000_000 else 1
         x_host = x[:nb].cpu().numpy() if N <= 1_000_000 else x[:1, : 16000 * 60].cpu().numpy()
         Wc = W if N <= 1_000_000 else ((x_host.shape[1] - 1 - L // 2) // stp if kind == "flt" else dsp_amd.num_frames(x_host.shape[1], L, stp, False))
-        v, desc = cpu_baseline(x_host, win_h, stp, nfft, kind, Wc)
-        out["cpu_baseline"] = {"value": v, "unit": "frames/s", "cores": 1, "kind": "port", "sample": desc}
+        out["cpu_baseline"] = cpu_baseline(x_host, win_h, stp, nfft, kind, Wc)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -22,6 +22,7 @@
 #include <math.h>
 
 #define PI_L 3.141592653589793238462643383279502884L
+static int orc_fftw_lock = 0;
 
 #define T float
 #define SFX s

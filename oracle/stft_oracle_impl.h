@@ -19,9 +19,34 @@
  * version, not in the reference tree).  Published definition: Y_k = sum_j X_j e^{-2 pi i jk/n},
  * unnormalised, output order r0..r_{n/2}, i_{(n+1)/2-1}..i_1.
  * mode 0: long-double evaluation rounded once to T (error below FFTW's own rounding error);
- * mode 1: arithmetic in T (the timed CPU baseline). */
+ * mode 1: arithmetic in T (the timed CPU baseline);
+ * mode 2: FFTW itself, where the benchmark found libfftw3(f) on the host and handed its three entry points
+ *         over with orc_set_fftw_s/_d: an FFTW_R2HC r2r plan with FFTW_ESTIMATE on this (in, out) pair, made
+ *         when the pair changes, i.e. once per call of stft, as the reference does (c/stft.c:53,77,158).
+ *         FFTW's planner is not thread-safe: plans are made and destroyed under a lock. */
+typedef void *(*FN(fftw_plan_fn))(int, T *, T *, int, unsigned);
+typedef void (*FN(fftw_exec_fn))(void *);
+static FN(fftw_plan_fn) FN(fftw_plan) = NULL;
+static FN(fftw_exec_fn) FN(fftw_exec) = NULL, FN(fftw_destroy) = NULL;
+void FN(set_fftw)(void *plan, void *exec, void *destroy)
+{
+    FN(fftw_plan) = (FN(fftw_plan_fn))plan; FN(fftw_exec) = (FN(fftw_exec_fn))exec; FN(fftw_destroy) = (FN(fftw_exec_fn))destroy;
+}
 static void FN(r2hc)(T *out, const T *in, size_t n, int mode)
 {
+    if (mode==2 && FN(fftw_plan))
+    {
+        static __thread void *plan = NULL; static __thread const T *pin = NULL; static __thread T *pout = NULL; static __thread size_t pn = 0u;
+        if (plan==NULL || pin!=in || pout!=out || pn!=n)
+        {
+            while (__atomic_exchange_n(&orc_fftw_lock,1,__ATOMIC_ACQUIRE)) { }
+            if (plan) { FN(fftw_destroy)(plan); }
+            plan = FN(fftw_plan)((int)n,(T*)in,out,0 /* FFTW_R2HC */,1u<<6 /* FFTW_ESTIMATE */);
+            __atomic_store_n(&orc_fftw_lock,0,__ATOMIC_RELEASE);
+            pin = in; pout = out; pn = n;
+        }
+        if (plan) { FN(fftw_exec)(plan); return; }
+    }
     if (mode==1 && n>=4u && !(n&(n-1u)))
     {
         const size_t m = n/2u;

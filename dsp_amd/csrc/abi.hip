@@ -14,7 +14,10 @@
 #include <list>
 #include <map>
 #include <memory>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -64,6 +67,13 @@ struct DevState {
     std::mutex ws_mu;
     void *ws[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t cap[4] = {0, 0, 0, 0};
+    // streamed form of the batched host-pointer entry points: per slot a pinned input and output stage and
+    // their device twins, three streams (copy in, compute, copy out), one event of each kind per slot
+    static constexpr int SLOTS = 3;
+    void *pin_in[SLOTS] = {}, *pin_out[SLOTS] = {}, *dev_in[SLOTS] = {}, *dev_out[SLOTS] = {};
+    size_t cap_in = 0, cap_out = 0;
+    hipStream_t st_in = nullptr, st_k = nullptr, st_out = nullptr;
+    hipEvent_t ev_in[SLOTS] = {}, ev_k[SLOTS] = {}, ev_out[SLOTS] = {};
 };
 DevState g_dev[MAX_DEV];
 
@@ -296,6 +306,157 @@ int run_fused(const char *fn, int dev, T *Yd, const T *Xd, const T *wd, const Fr
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// host-pointer forms
+// ------------------------------------------------------------------------------------------------
+// Copies between the caller's (pageable) arrays and pinned staging memory, split over a few threads: one
+// thread moves ~10 GB/s, the PCIe link takes ~55 GB/s in each direction at once.
+class CopyPool {
+public:
+    static CopyPool &get() { static CopyPool p; return p; }
+    // dst[r][0..row) = src[r][0..row) for r < rows (row strides in bytes); returns when all of it is done
+    void copy_rows(void *dst, size_t dst_stride, const void *src, size_t src_stride, size_t row, size_t rows)
+    {
+        const size_t total = row * rows;
+        if (total < (size_t)4 << 20 || workers_.empty()) { do_range(dst, dst_stride, src, src_stride, row, 0, total); return; }
+        const size_t parts = workers_.size() + 1;
+        const size_t per = ((total + parts - 1) / parts + 4095) & ~(size_t)4095;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            job_ = [=](size_t i) { const size_t a = std::min(total, i * per), b = std::min(total, a + per); if (b > a) { do_range(dst, dst_stride, src, src_stride, row, a, b); } };
+            pending_ = workers_.size();
+            ++gen_;
+        }
+        cv_.notify_all();
+        job_(workers_.size());                              // the caller takes the last part
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [&] { return pending_ == 0; });
+    }
+    ~CopyPool()
+    {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; ++gen_; }
+        cv_.notify_all();
+        for (auto &t : workers_) { t.join(); }
+    }
+private:
+    CopyPool()
+    {
+        unsigned n = std::thread::hardware_concurrency();
+        if (const char *e = getenv("OMP_NUM_THREADS")) { const int v = atoi(e); if (v > 0 && (unsigned)v < n) { n = (unsigned)v; } }
+        if (const char *e = getenv("DSP_COPY_THREADS")) { const int v = atoi(e); if (v > 0) { n = (unsigned)v; } }
+        n = std::min(n, 12u);
+        for (unsigned i = 0; i + 1 < n; ++i) { workers_.emplace_back([this, i] { loop(i); }); }
+    }
+    // bytes [a, b) of the dense sequence of rows
+    static void do_range(void *dst, size_t ds, const void *src, size_t ss, size_t row, size_t a, size_t b)
+    {
+        if (ds == row && ss == row) { memcpy((char *)dst + a, (const char *)src + a, b - a); return; }
+        while (a < b) {
+            const size_t r = a / row, o = a - r * row, n = std::min(row - o, b - a);
+            memcpy((char *)dst + r * ds + o, (const char *)src + r * ss + o, n);
+            a += n;
+        }
+    }
+    void loop(size_t i)
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            std::function<void(size_t)> job;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) { return; }
+                job = job_;
+            }
+            job(i);
+            { std::lock_guard<std::mutex> lk(mu_); if (--pending_ == 0) { done_.notify_all(); } }
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    std::function<void(size_t)> job_;
+    size_t pending_ = 0;
+    unsigned long long gen_ = 0;
+    bool stop_ = false;
+};
+
+
+// Streamed form for batches: signals go through in chunks, chunk c being staged and copied in while chunk
+// c - 1 is transformed and chunk c - 2 is copied out and unstaged (pinned stages, three streams).  The kernel
+// sees each chunk as a dense batch of its own, so the result is the batched device path's, bit for bit.
+constexpr size_t STREAM_MIN_BYTES = (size_t)64 << 20;      // below this the plain three copies are faster
+constexpr size_t STREAM_CHUNK_BYTES = (size_t)48 << 20;    // input + output bytes of a chunk
+template <typename T>
+int run_fused_host_streamed(const char *fn, int dev, T *Y, const T *X, const T *win, const FrameDesc &d)
+{
+    DevState &st = g_dev[dev];
+    const size_t F = (size_t)d.nfft / 2 + 1, N = (size_t)d.N, W = (size_t)d.W, B = (size_t)d.B;
+    const size_t in_sig = N * sizeof(T), out_sig = W * F * sizeof(T);
+    size_t cb = STREAM_CHUNK_BYTES / (in_sig + out_sig);
+    cb = std::max<size_t>(1, std::min(cb, (B + 1) / 2));
+    const size_t nchunks = (B + cb - 1) / cb;
+    constexpr int S = DevState::SLOTS;
+    if (st.cap_in < cb * in_sig || st.cap_out < cb * out_sig) {
+        HIPCHK(fn, hipDeviceSynchronize());
+        for (int i = 0; i < S; ++i) {
+            if (st.pin_in[i]) { (void)hipHostFree(st.pin_in[i]); (void)hipHostFree(st.pin_out[i]); (void)hipFree(st.dev_in[i]); (void)hipFree(st.dev_out[i]); }
+            st.pin_in[i] = st.pin_out[i] = st.dev_in[i] = st.dev_out[i] = nullptr;
+        }
+        st.cap_in = st.cap_out = 0;
+        for (int i = 0; i < S; ++i) {
+            HIPCHK(fn, hipHostMalloc(&st.pin_in[i], cb * in_sig, hipHostMallocDefault));
+            HIPCHK(fn, hipHostMalloc(&st.pin_out[i], cb * out_sig, hipHostMallocDefault));
+            HIPCHK(fn, hipMalloc(&st.dev_in[i], cb * in_sig));
+            HIPCHK(fn, hipMalloc(&st.dev_out[i], cb * out_sig));
+        }
+        st.cap_in = cb * in_sig; st.cap_out = cb * out_sig;
+    }
+    if (!st.st_in) {
+        HIPCHK(fn, hipStreamCreateWithFlags(&st.st_in, hipStreamNonBlocking));
+        HIPCHK(fn, hipStreamCreateWithFlags(&st.st_k, hipStreamNonBlocking));
+        HIPCHK(fn, hipStreamCreateWithFlags(&st.st_out, hipStreamNonBlocking));
+        for (int i = 0; i < S; ++i) {
+            HIPCHK(fn, hipEventCreateWithFlags(&st.ev_in[i], hipEventDisableTiming));
+            HIPCHK(fn, hipEventCreateWithFlags(&st.ev_k[i], hipEventDisableTiming));
+            HIPCHK(fn, hipEventCreateWithFlags(&st.ev_out[i], hipEventDisableTiming));
+        }
+    }
+    void *dw;
+    if (ws_reserve(fn, st, 2, (size_t)d.L * sizeof(T), dw)) { return 1; }
+    HIPCHK(fn, hipMemcpy(dw, win, (size_t)d.L * sizeof(T), hipMemcpyHostToDevice));
+    CopyPool &pool = CopyPool::get();
+    constexpr size_t LAG = S - 1;
+    int rc = 0;
+    for (size_t c = 0; c < nchunks + LAG; ++c) {
+        if (c < nchunks && !rc) {
+            const int sl = (int)(c % S);
+            const size_t b0 = c * cb, nb = std::min(cb, B - b0);
+            // (the slot's stages and device buffers are free: chunk c - S was unstaged in the iteration before)
+            pool.copy_rows(st.pin_in[sl], in_sig, X + b0 * (size_t)d.ldx, (size_t)d.ldx * sizeof(T), in_sig, nb);
+            HIPCHK(fn, hipMemcpyAsync(st.dev_in[sl], st.pin_in[sl], nb * in_sig, hipMemcpyHostToDevice, st.st_in));
+            HIPCHK(fn, hipEventRecord(st.ev_in[sl], st.st_in));
+            HIPCHK(fn, hipStreamWaitEvent(st.st_k, st.ev_in[sl], 0));
+            FrameDesc dc = d;
+            dc.B = (int)nb; dc.ldx = (long long)N;
+            rc = run_fused<T>(fn, dev, (T *)st.dev_out[sl], (const T *)st.dev_in[sl], (const T *)dw, dc, st.st_k, nullptr, nullptr);
+            HIPCHK(fn, hipEventRecord(st.ev_k[sl], st.st_k));
+            HIPCHK(fn, hipStreamWaitEvent(st.st_out, st.ev_k[sl], 0));
+            HIPCHK(fn, hipMemcpyAsync(st.pin_out[sl], st.dev_out[sl], nb * out_sig, hipMemcpyDeviceToHost, st.st_out));
+            HIPCHK(fn, hipEventRecord(st.ev_out[sl], st.st_out));
+        }
+        if (c >= LAG) {
+            const size_t cd = c - LAG;
+            const int sl = (int)(cd % S);
+            const size_t b0 = cd * cb, nb = std::min(cb, B - b0);
+            HIPCHK(fn, hipEventSynchronize(st.ev_out[sl]));
+            if (!rc) { pool.copy_rows(Y + b0 * W * F, out_sig, st.pin_out[sl], out_sig, out_sig, nb); }
+        }
+    }
+    return rc;
+}
+
 // host-pointer form: copy in, compute on the null stream, copy out (blocking)
 template <typename T>
 int run_fused_host(const char *fn, int dev, T *Y, const T *X, const T *win, FrameDesc &d, size_t x_elems)
@@ -305,6 +466,10 @@ int run_fused_host(const char *fn, int dev, T *Y, const T *X, const T *win, Fram
     std::lock_guard<std::mutex> lk(st.ws_mu);
     const size_t F = (size_t)d.nfft / 2 + 1;
     const size_t y_elems = (size_t)d.B * (size_t)d.W * F;
+    if (d.B >= 2 && d.tbl == nullptr && (x_elems + y_elems) * sizeof(T) >= STREAM_MIN_BYTES &&
+        ((size_t)d.N + (size_t)d.W * F) * sizeof(T) <= ((size_t)512 << 20)) {
+        return run_fused_host_streamed<T>(fn, dev, Y, X, win, d);
+    }
     void *dx, *dy, *dw;
     if (ws_reserve(fn, st, 0, x_elems * sizeof(T), dx)) { return 1; }
     if (ws_reserve(fn, st, 1, y_elems * sizeof(T), dy)) { return 1; }

@@ -491,6 +491,30 @@ def test_batch_host_and_device(O, D, dt):
     np.testing.assert_array_equal(D.fft_power_dev(zt).cpu().numpy(), D.fft_power(zt.cpu().numpy()))
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_batch_host_streamed_equals_device(O, D, dt):
+    """Batches of 64 MB and more go through the host-pointer entry points in chunks (pinned stages, copies
+    overlapped with the kernel): same bits as the device-resident call on the whole batch, for dense and for
+    strided rows, and for a batch that does not divide into equal chunks."""
+    import torch
+    rng = np.random.default_rng(5)
+    B, N = (67, 160000) if dt == np.float32 else (35, 150000)
+    buf = (rng.standard_normal((B, N + 24)) * 0.1).astype(dt)
+    win = D.hann(400, dt)
+    for xs in (np.ascontiguousarray(buf[:, :N]), buf[:, 8:N + 8]):
+        Yh = D.stft_batch(xs, win, 160)
+        Yd = D.stft_dev(torch.from_numpy(np.ascontiguousarray(xs)).cuda(), torch.from_numpy(win).cuda(), 160)
+        torch.cuda.synchronize()
+        assert np.array_equal(Yh, Yd.cpu().numpy())
+    rc, Yref = O.stft(np.ascontiguousarray(buf[B - 1, :N]), win, 160, 512, exact=False)
+    check_spec(O, Yh_last := D.stft_batch(np.ascontiguousarray(buf[:, :N]), win, 160)[B - 1], Yref)
+    # twice in a row with different sizes (the stages are reused and regrown)
+    Y2 = D.stft_batch(np.ascontiguousarray(buf[:40, :N]), win, 160, mn0=True, lg=True)
+    Y2d = D.stft_dev(torch.from_numpy(np.ascontiguousarray(buf[:40, :N])).cuda(), torch.from_numpy(win).cuda(), 160, mn0=True, lg=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(Y2, Y2d.cpu().numpy())
+
+
 def test_nan_stays_in_its_own_frames(O, D):
     """A NaN sample must only reach the frames that contain it (reflection included)."""
     x = signal(1, 8000, np.float32)

@@ -348,17 +348,33 @@ def _stream_ptr(t):
 
 
 def stft_dev(x, win, stp=160, snip_edges=False, mn0=False, amp=False, lg=False, nfft=None, out=None):
-    """dsp_stft_batch_dev_s / _d.  x: device tensor [B, N] (unit stride along N), win: device tensor
-    [L]; returns the device tensor Y[B, W, F].  Enqueued on torch's current stream, not synchronised."""
+    """dsp_stft_batch_dev_s / _d.  x: device tensor [B, N], win: device tensor [L]; returns the device tensor
+    Y[B, W, F].  Enqueued on torch's current stream, not synchronised.  A view with a sample stride (such as
+    t.T of a row-major [N, C] tensor of interleaved channels) goes through dsp_stft_batch_dev_strided_s / _d."""
     import torch
     if x.dim() == 1:
         x = x.unsqueeze(0)
-    if not x.is_cuda or x.dim() != 2 or x.stride(1) != 1:
-        raise ValueError("x must be a device tensor [B, N] with unit stride along N")
+    if not x.is_cuda or x.dim() != 2 or x.stride(1) < 1 or x.stride(0) < 0:
+        raise ValueError("x must be a device tensor [B, N] with positive strides")
     s = _torch_sfx(x)
     win = win.to(device=x.device, dtype=x.dtype).contiguous()
     B, N = x.shape
     ldx = x.stride(0) if B > 1 else N
+    if x.stride(1) != 1:
+        L = win.numel()
+        nfft = nextpow2(L) if nfft is None else int(nfft)
+        W = num_frames(N, L, stp, snip_edges)
+        if out is None:
+            out = torch.empty((B, W, nfft // 2 + 1), dtype=x.dtype, device=x.device)
+        else:
+            _check_out(out, (B, W, nfft // 2 + 1), x, "[B, W, F]")
+        with torch.cuda.device(x.device):
+            rc = getattr(lib(), f"dsp_stft_batch_dev_strided_{s}")(C.c_void_p(out.data_ptr()), C.c_void_p(x.data_ptr()),
+                                                                   C.c_void_p(win.data_ptr()), B, N, x.stride(0) if B > 1 else 0,
+                                                                   x.stride(1), L, nfft, stp, int(bool(snip_edges)), int(bool(mn0)),
+                                                                   int(bool(amp)), int(bool(lg)), _stream_ptr(x))
+        _check(rc, f"dsp_stft_batch_dev_strided_{s}")
+        return out
     L = win.numel()
     nfft = nextpow2(L) if nfft is None else int(nfft)
     W = num_frames(N, L, stp, snip_edges)
@@ -420,12 +436,13 @@ def pow_compress_dev(x, p, preg=0.0, out=None):
 
 
 def stft_flt_dev(x, win, W, c0=0.0, stp=160.0, mn0=False, amp=False, lg=False, nfft=None, out=None):
-    """dsp_stft_flt_batch_dev_s / _d.  x: device tensor [B, N]; returns Y[B, W, F]."""
+    """dsp_stft_flt_batch_dev_s / _d.  x: device tensor [B, N]; returns Y[B, W, F].  A view with a sample stride goes
+    through dsp_stft_flt_batch_dev_strided_s / _d."""
     import torch
     if x.dim() == 1:
         x = x.unsqueeze(0)
-    if not x.is_cuda or x.dim() != 2 or x.stride(1) != 1:
-        raise ValueError("x must be a device tensor [B, N] with unit stride along N")
+    if not x.is_cuda or x.dim() != 2 or x.stride(1) < 1 or x.stride(0) < 0:
+        raise ValueError("x must be a device tensor [B, N] with positive strides")
     s = _torch_sfx(x)
     win = win.to(device=x.device, dtype=x.dtype).contiguous()
     B, N = x.shape
@@ -436,6 +453,14 @@ def stft_flt_dev(x, win, W, c0=0.0, stp=160.0, mn0=False, amp=False, lg=False, n
         out = torch.empty((B, W, nfft // 2 + 1), dtype=x.dtype, device=x.device)
     else:
         _check_out(out, (B, W, nfft // 2 + 1), x, "[B, W, F]")
+    if x.stride(1) != 1:
+        with torch.cuda.device(x.device):
+            rc = getattr(lib(), f"dsp_stft_flt_batch_dev_strided_{s}")(C.c_void_p(out.data_ptr()), C.c_void_p(x.data_ptr()),
+                                                                       C.c_void_p(win.data_ptr()), B, N, x.stride(0) if B > 1 else 0,
+                                                                       x.stride(1), L, W, nfft, c0, stp, int(bool(mn0)), int(bool(amp)),
+                                                                       int(bool(lg)), _stream_ptr(x))
+        _check(rc, f"dsp_stft_flt_batch_dev_strided_{s}")
+        return out
     with torch.cuda.device(x.device):
         rc = getattr(lib(), f"dsp_stft_flt_batch_dev_{s}")(C.c_void_p(out.data_ptr()), C.c_void_p(x.data_ptr()),
                                                            C.c_void_p(win.data_ptr()), B, N, ldx, L, W, nfft, c0, stp,

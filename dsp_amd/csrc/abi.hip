@@ -611,6 +611,27 @@ int stft_dev_noalloc(const char *fn, float *Yd, const float *Xd, const float *wd
     return run_fused<float>(fn, dev, Yd, Xd, wd, d, (hipStream_t)stream, tw, take);
 }
 
+// Device-resident forms for signals with a sample stride (multivariate tensors with interleaved channels): the
+// signals are gathered into a dense [B][N] buffer allocated and freed in the stream's order, then transformed
+// as a dense batch (same bits as the dense entry point on the gathered signals).
+template <typename T, typename Run>
+int with_dense_signals(const char *fn, const T *Xd, size_t B, size_t N, size_t ldx, size_t incx, void *stream, Run run)
+{
+    if (incx == 1) { return run(Xd, ldx); }
+    if (incx == 0) { fprintf(stderr, "error in %s: incx must be positive\n", fn); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    void *dense = nullptr;
+    HIPCHK(fn, hipMallocAsync(&dense, B * N * sizeof(T), s));
+    int rc = 0;
+    if (hipError_t e = launch_gather_signals<T>((T *)dense, Xd, N, B, ldx, incx, s); e != hipSuccess) {
+        fprintf(stderr, "error in %s: hip call failed (gather of the signals): %s\n", fn, hipGetErrorString(e));
+        rc = 1;
+    }
+    if (!rc) { rc = run((const T *)dense, N); }
+    HIPCHK(fn, hipFreeAsync(dense, s));
+    return rc;
+}
+
 // power compression as an epilogue; checks and messages of reference c/pow_compress.c:25-26,30-46
 template <typename T>
 int pc_epilogue(const char *fn, T p, T preg, Epilogue &e)
@@ -1113,6 +1134,39 @@ int dsp_stft_batch_dev_d(double *Y_dev, const double *X_dev, const double *win_d
 
 int dsp_stft_batch_dev_noalloc_s(float *Y_dev, const float *X_dev, const float *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, void *stream)
 { return stft_dev_noalloc("dsp_stft_batch_dev_noalloc_s", Y_dev, X_dev, win_dev, B, N, ldx, L, nfft, stp, snip_edges, mn0, amp, lg, stream); }
+
+int dsp_stft_batch_dev_strided_s(float *Y_dev, const float *X_dev, const float *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t incx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, void *stream)
+{
+    const char *fn = "dsp_stft_batch_dev_strided_s";
+    if (B == 0 || N == 0 || !X_dev) { return stft_dev<float>(fn, Y_dev, X_dev, win_dev, B, N, N, L, nfft, stp, snip_edges, mn0, amp, lg, stream); }
+    int dev;
+    if (use_device(fn, dev)) { return 1; }
+    return with_dense_signals<float>(fn, X_dev, B, N, ldx, incx, stream, [&](const float *xd, size_t ld) { return stft_dev<float>(fn, Y_dev, xd, win_dev, B, N, ld, L, nfft, stp, snip_edges, mn0, amp, lg, stream); });
+}
+int dsp_stft_batch_dev_strided_d(double *Y_dev, const double *X_dev, const double *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t incx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, void *stream)
+{
+    const char *fn = "dsp_stft_batch_dev_strided_d";
+    if (B == 0 || N == 0 || !X_dev) { return stft_dev<double>(fn, Y_dev, X_dev, win_dev, B, N, N, L, nfft, stp, snip_edges, mn0, amp, lg, stream); }
+    int dev;
+    if (use_device(fn, dev)) { return 1; }
+    return with_dense_signals<double>(fn, X_dev, B, N, ldx, incx, stream, [&](const double *xd, size_t ld) { return stft_dev<double>(fn, Y_dev, xd, win_dev, B, N, ld, L, nfft, stp, snip_edges, mn0, amp, lg, stream); });
+}
+int dsp_stft_flt_batch_dev_strided_s(float *Y_dev, const float *X_dev, const float *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t incx, const size_t L, const size_t W, const size_t nfft, const float c0, const float stp, const int mn0, const int amp, const int lg, void *stream)
+{
+    const char *fn = "dsp_stft_flt_batch_dev_strided_s";
+    if (B == 0 || N == 0 || !X_dev) { return stft_flt_dev<float>(fn, Y_dev, X_dev, win_dev, B, N, N, L, W, nfft, c0, stp, mn0, amp, lg, stream); }
+    int dev;
+    if (use_device(fn, dev)) { return 1; }
+    return with_dense_signals<float>(fn, X_dev, B, N, ldx, incx, stream, [&](const float *xd, size_t ld) { return stft_flt_dev<float>(fn, Y_dev, xd, win_dev, B, N, ld, L, W, nfft, c0, stp, mn0, amp, lg, stream); });
+}
+int dsp_stft_flt_batch_dev_strided_d(double *Y_dev, const double *X_dev, const double *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t incx, const size_t L, const size_t W, const size_t nfft, const double c0, const double stp, const int mn0, const int amp, const int lg, void *stream)
+{
+    const char *fn = "dsp_stft_flt_batch_dev_strided_d";
+    if (B == 0 || N == 0 || !X_dev) { return stft_flt_dev<double>(fn, Y_dev, X_dev, win_dev, B, N, N, L, W, nfft, c0, stp, mn0, amp, lg, stream); }
+    int dev;
+    if (use_device(fn, dev)) { return 1; }
+    return with_dense_signals<double>(fn, X_dev, B, N, ldx, incx, stream, [&](const double *xd, size_t ld) { return stft_flt_dev<double>(fn, Y_dev, xd, win_dev, B, N, ld, L, W, nfft, c0, stp, mn0, amp, lg, stream); });
+}
 
 int dsp_stft_flt_batch_dev_s(float *Y_dev, const float *X_dev, const float *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t W, const size_t nfft, const float c0, const float stp, const int mn0, const int amp, const int lg, void *stream)
 { return stft_flt_dev<float>("dsp_stft_flt_batch_dev_s", Y_dev, X_dev, win_dev, B, N, ldx, L, W, nfft, c0, stp, mn0, amp, lg, stream); }

@@ -184,6 +184,46 @@ template hipError_t launch_stft_direct<double>(double *, const double *, const d
 // unfused steps: fft_power, frame_univar[_flt], apply_win, fft_fftw_r2hc
 // =================================================================================================
 
+// Signals of a multivariate tensor laid out with a sample stride (reference tensor convention: stride K along the
+// transformed axis, c/fft.fftw.r2hc.c:63-65, c/apply_win.c:46-74; a row-major [N][C] tensor has incx = C, ldx = 1)
+// gathered into the dense [B][N] layout the fused kernels stream: Y[b][n] = X[b ldx + n incx].  Tiles of 64 signals
+// x 64 samples through LDS: reads run along the signals (one sample of 64 interleaved channels is contiguous),
+// writes along the samples; 2 elements of traffic per sample.
+template <typename T>
+__global__ __launch_bounds__(256) void gather_signals_kernel(T *__restrict__ Y, const T *__restrict__ X, const size_t N, const size_t B,
+                                                           const size_t ldx, const size_t incx, const size_t tiles_n, const size_t tiles)
+{
+    __shared__ T tile[64][65];
+    const int lo = threadIdx.x & 63, hi = threadIdx.x >> 6;
+    for (size_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const size_t b0 = (t / tiles_n) * 64, n0 = (t % tiles_n) * 64;
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const size_t n = n0 + hi + 4 * i, b = b0 + lo;
+            tile[lo][hi + 4 * i] = (n < N && b < B) ? X[b * ldx + n * incx] : T(0);
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const size_t b = b0 + hi + 4 * i, n = n0 + lo;
+            if (b < B && n < N) { Y[b * N + n] = tile[hi + 4 * i][lo]; }
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T>
+hipError_t launch_gather_signals(T *Y, const T *X, size_t N, size_t B, size_t ldx, size_t incx, hipStream_t s)
+{
+    if (N == 0 || B == 0) { return hipSuccess; }
+    const size_t tiles_n = (N + 63) / 64, tiles = tiles_n * ((B + 63) / 64);
+    const size_t grid = tiles < 256 * 16 ? tiles : 256 * 16;
+    hipLaunchKernelGGL(gather_signals_kernel<T>, dim3((unsigned)grid), dim3(256), 0, s, Y, X, N, B, ldx, incx, tiles_n, tiles);
+    return hipGetLastError();
+}
+template hipError_t launch_gather_signals<float>(float *, const float *, size_t, size_t, size_t, size_t, hipStream_t);
+template hipError_t launch_gather_signals<double>(double *, const double *, size_t, size_t, size_t, size_t, hipStream_t);
+
 // reference c/fft_power.c:21 -- Y[n] = re^2 + im^2; pure streaming, 3 elements of traffic per value
 template <typename T>
 __global__ __launch_bounds__(256) void fft_power_kernel(T *__restrict__ Y, const T *__restrict__ X, const size_t N)

@@ -217,6 +217,8 @@ enum WindowKind { WIN_HANN = 0, WIN_HAMMING, WIN_POVEY, WIN_BLACKMANHARRIS, WIN_
                   WIN_RECTANGULAR, WIN_FLATTOP, WIN_GAUSS, WIN_TUKEY, WIN_PLANCK, WIN_COUNT };
 template <typename T> hipError_t launch_window(T *Y, size_t L, int kind, int norm, T par, int flag, hipStream_t s);
 template <typename T> hipError_t launch_fft_power(T *Y, const T *X, size_t N, hipStream_t s);
+// Y[b][n] = X[b ldx + n incx], dense [B][N]
+template <typename T> hipError_t launch_gather_signals(T *Y, const T *X, size_t N, size_t B, size_t ldx, size_t incx, hipStream_t s);
 template <typename T> hipError_t launch_pow_compress(T *Y, const T *X, size_t N, const Epilogue &e, hipStream_t s);
 // win != nullptr (E == 1 only): every frame is multiplied by the L window values
 template <typename T> hipError_t launch_frames(T *Y, const T *X, const T *win, const FrameDesc &d, int E, hipStream_t s);

@@ -190,7 +190,19 @@ int dsp_stft_batch_dev_noalloc_s (float *Y_dev, const float *X_dev, const float 
 int dsp_stft_flt_batch_dev_s (float *Y_dev, const float *X_dev, const float *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t W, const size_t nfft, const float c0, const float stp, const int mn0, const int amp, const int lg, void *stream);
 int dsp_stft_flt_batch_dev_d (double *Y_dev, const double *X_dev, const double *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t W, const size_t nfft, const double c0, const double stp, const int mn0, const int amp, const int lg, void *stream);
 
-/* Batched host-pointer forms: X[b*ldx + n], Y[b][W][F]; copies in, computes, copies out. */
+/* The same for signals with a sample stride: sample n of signal b at X_dev[b*ldx + n*incx].  A multivariate
+ * tensor with interleaved channels (row-major [N][C]: the reference's tensors have stride K along the
+ * transformed axis, c/fft.fftw.r2hc.c:63-65) is B = C, ldx = 1, incx = C.  The signals are first gathered into a
+ * dense [B][N] buffer that lives for the call (allocated and freed in `stream`'s order, B*N elements), so the
+ * output has the bits of the dense entry point; incx = 1 is the dense entry point itself. */
+int dsp_stft_batch_dev_strided_s (float *Y_dev, const float *X_dev, const float *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t incx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, void *stream);
+int dsp_stft_batch_dev_strided_d (double *Y_dev, const double *X_dev, const double *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t incx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, void *stream);
+int dsp_stft_flt_batch_dev_strided_s (float *Y_dev, const float *X_dev, const float *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t incx, const size_t L, const size_t W, const size_t nfft, const float c0, const float stp, const int mn0, const int amp, const int lg, void *stream);
+int dsp_stft_flt_batch_dev_strided_d (double *Y_dev, const double *X_dev, const double *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t incx, const size_t L, const size_t W, const size_t nfft, const double c0, const double stp, const int mn0, const int amp, const int lg, void *stream);
+
+/* Batched host-pointer forms: X[b*ldx + n], Y[b][W][F]; copies in, computes, copies out.  Batches of 64 MB and
+ * more are streamed through pinned stages in chunks of signals (copy in, kernel and copy out overlapped; the
+ * staging copies run on up to 12 threads, DSP_COPY_THREADS overrides). */
 int dsp_stft_batch_s (float *Y, const float *X, const float *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg);
 int dsp_stft_batch_d (double *Y, const double *X, const double *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg);
 

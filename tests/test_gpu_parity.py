@@ -515,6 +515,33 @@ def test_batch_host_streamed_equals_device(O, D, dt):
     assert np.array_equal(Y2, Y2d.cpu().numpy())
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_interleaved_channels_equal_channels_alone(O, D, dt):
+    """A multivariate tensor with interleaved channels, row-major [N][C] (sample stride C, channel stride 1: the
+    reference's tensors have stride K along the transformed axis, c/fft.fftw.r2hc.c:63-65), through the strided
+    entry points: every channel has the bits of the same channel transformed from a dense copy, and matches the
+    oracle; channel counts that are no multiple of the gather tile, a sub-block of the channels, both framings."""
+    import torch
+    tdt = torch.float32 if dt == np.float32 else torch.float64
+    g = torch.Generator(device="cuda").manual_seed(17)
+    win = torch.from_numpy(D.povey(400, dt)).cuda()
+    for (N, Cc) in [(48000, 64), (20011, 7), (9000, 130)]:
+        t = torch.randn((N, Cc), generator=g, device="cuda", dtype=tdt)           # [N][C]
+        x = t.T                                                                    # [C][N] view, stride (1, C)
+        dense = x.contiguous()
+        Y = D.stft_dev(x, win, 160)
+        Yd = D.stft_dev(dense, win, 160)
+        W = int((N - 1 - 200) // 160.5)
+        Z = D.stft_flt_dev(x, win, W, 200.0, 160.5, mn0=True)
+        Zd = D.stft_flt_dev(dense, win, W, 200.0, 160.5, mn0=True)
+        sub = D.stft_dev(x[1:5], win, 160)                                         # a block of the channels
+        torch.cuda.synchronize()
+        assert torch.equal(Y, Yd) and torch.equal(Z, Zd) and torch.equal(sub, Yd[1:5])
+        c = Cc - 1
+        rc, Yref = O.stft(dense[c].cpu().numpy(), win.cpu().numpy(), 160, 512, exact=False)
+        check_spec(O, Y[c].cpu().numpy(), Yref)
+
+
 def test_nan_stays_in_its_own_frames(O, D):
     """A NaN sample must only reach the frames that contain it (reflection included)."""
     x = signal(1, 8000, np.float32)

@@ -95,6 +95,63 @@ def stft_batch(x, win, stp=160, snip_edges=False, mn0=False, amp=False, lg=False
     return Y
 
 
+def shard_range(B, rank, world):
+    """dsp_shard_range: the block [lo, hi) of B signals that GPU `rank` of `world` takes."""
+    lo, hi = C.c_size_t(0), C.c_size_t(0)
+    lib().dsp_shard_range(B, rank, world, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+def stft_multi(x, win, stp=160, snip_edges=False, mn0=False, amp=False, lg=False, nfft=None, devices=(0,)):
+    """dsp_stft_multi_s / _d: the host batch x[B, N] split over the GPUs in `devices`, one thread per GPU."""
+    x = np.ascontiguousarray(x)
+    s = _real_sfx(x.dtype)
+    win = np.ascontiguousarray(win, dtype=x.dtype)
+    B, N = x.shape
+    L = win.size
+    nfft = nextpow2(L) if nfft is None else int(nfft)
+    W = num_frames(N, L, stp, snip_edges)
+    Y = np.empty((B, W, nfft // 2 + 1), dtype=x.dtype)
+    devs = (C.c_int * len(devices))(*devices)
+    rc = getattr(lib(), f"dsp_stft_multi_{s}")(_p(Y), _p(x), _p(win), B, N, N, L, nfft, stp, int(bool(snip_edges)), int(bool(mn0)),
+                                               int(bool(amp)), int(bool(lg)), C.cast(devs, C.c_void_p), len(devices))
+    _check(rc, f"dsp_stft_multi_{s}")
+    return Y
+
+
+def stft_multi_dev(x_blocks, wins, stp=160, snip_edges=False, mn0=False, amp=False, lg=False, nfft=None, devices=None, gather=True):
+    """dsp_stft_multi_dev_s / _d.  x_blocks[g]: GPU g's block of the batch (a dense device tensor [hi-lo, N] on
+    devices[g], blocks as shard_range gives them), wins[g] the window on that GPU.  Returns (list of output blocks,
+    Y_all on devices[0] or None)."""
+    import torch
+    ngpu = len(x_blocks)
+    devices = list(range(ngpu)) if devices is None else list(devices)
+    B = sum(int(b.shape[0]) for b in x_blocks)
+    N = int(x_blocks[0].shape[1])
+    s = _torch_sfx(x_blocks[0])
+    L = wins[0].numel()
+    nfft = nextpow2(L) if nfft is None else int(nfft)
+    W = num_frames(N, L, stp, snip_edges)
+    F = nfft // 2 + 1
+    for g, xb in enumerate(x_blocks):
+        lo, hi = shard_range(B, g, ngpu)
+        if tuple(xb.shape) != (hi - lo, N) or not xb.is_contiguous():
+            raise ValueError(f"block {g} must be a dense [{hi - lo}, {N}] tensor")
+    ys = [torch.empty((xb.shape[0], W, F), dtype=xb.dtype, device=xb.device) for xb in x_blocks]
+    y_all = torch.empty((B, W, F), dtype=x_blocks[0].dtype, device=x_blocks[0].device) if gather else None
+    vp = C.c_void_p
+    yp = (vp * ngpu)(*[y.data_ptr() for y in ys])
+    xp = (vp * ngpu)(*[xb.data_ptr() for xb in x_blocks])
+    wp = (vp * ngpu)(*[w.data_ptr() for w in wins])
+    devs = (C.c_int * ngpu)(*devices)
+    torch.cuda.synchronize()
+    rc = getattr(lib(), f"dsp_stft_multi_dev_{s}")(C.cast(yp, vp), C.cast(xp, vp), C.cast(wp, vp), vp(y_all.data_ptr() if gather else 0), B, N, N, L,
+                                                   nfft, stp, int(bool(snip_edges)), int(bool(mn0)), int(bool(amp)), int(bool(lg)),
+                                                   C.cast(devs, vp), ngpu)
+    _check(rc, f"dsp_stft_multi_dev_{s}")
+    return ys, y_all
+
+
 def stft_flt(x, win, W, c0=0.0, stp=160.0, mn0=False, amp=False, lg=False, nfft=None):
     """stft_flt_s / stft_flt_d.  Returns Y[W, nfft//2+1]."""
     x = np.ascontiguousarray(x)

@@ -317,6 +317,7 @@ public:
     // dst[r][0..row) = src[r][0..row) for r < rows (row strides in bytes); returns when all of it is done
     void copy_rows(void *dst, size_t dst_stride, const void *src, size_t src_stride, size_t row, size_t rows)
     {
+        std::lock_guard<std::mutex> one_caller(call_mu_);      // (the threads of a multi-GPU call take turns)
         const size_t total = row * rows;
         if (total < (size_t)4 << 20 || workers_.empty()) { do_range(dst, dst_stride, src, src_stride, row, 0, total); return; }
         const size_t parts = workers_.size() + 1;
@@ -374,7 +375,7 @@ private:
         }
     }
     std::vector<std::thread> workers_;
-    std::mutex mu_;
+    std::mutex mu_, call_mu_;
     std::condition_variable cv_, done_;
     std::function<void(size_t)> job_;
     size_t pending_ = 0;
@@ -629,6 +630,96 @@ int with_dense_signals(const char *fn, const T *Xd, size_t B, size_t N, size_t l
     }
     if (!rc) { rc = run((const T *)dense, N); }
     HIPCHK(fn, hipFreeAsync(dense, s));
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// several GPUs from one process: signals split in contiguous blocks, no reduction
+// ------------------------------------------------------------------------------------------------
+void shard_range(size_t B, size_t rank, size_t world, size_t &lo, size_t &hi)
+{
+    const size_t per = world ? (B + world - 1) / world : B;
+    lo = std::min(B, rank * per);
+    hi = std::min(B, lo + per);
+}
+
+// host pointers: GPU g transforms signals [lo_g, hi_g) on a thread of its own (the streamed host path), each
+// writing its block of Y: the gather is the copy out
+template <typename T>
+int stft_multi_host(const char *fn, T *Y, const T *X, const T *win, size_t B, size_t N, size_t ldx, size_t L, size_t nfft, size_t stp,
+                    int snip_edges, int mn0, int amp, int lg, const int *devices, int ngpu)
+{
+    FrameDesc d; size_t W;
+    if (stft_desc(fn, d, B, N, ldx, L, nfft, stp, snip_edges, mn0, amp, lg, W)) { return 1; }
+    if (ngpu < 1 || ngpu > MAX_DEV) { fprintf(stderr, "error in %s: ngpu must be in [1 %d]\n", fn, MAX_DEV); return 1; }
+    if (B > 1 && ldx < N) { fprintf(stderr, "error in %s: ldx must be >= N\n", fn); return 1; }
+    if (W == 0 || B == 0) { return 0; }
+    int ndev = 0;
+    HIPCHK(fn, hipGetDeviceCount(&ndev));
+    for (int g = 0; g < ngpu; ++g) {
+        const int dv = devices ? devices[g] : g;
+        if (dv < 0 || dv >= ndev) { fprintf(stderr, "error in %s: device %d not available\n", fn, dv); return 1; }
+    }
+    const size_t F = nfft / 2 + 1;
+    const int intended = tl_flt_intended, generic = tl_force_generic;
+    std::vector<int> rcs(ngpu, 0);
+    std::vector<std::thread> th;
+    for (int g = 0; g < ngpu; ++g) {
+        th.emplace_back([&, g] {
+            size_t lo, hi;
+            shard_range(B, (size_t)g, (size_t)ngpu, lo, hi);
+            if (hi == lo) { return; }
+            tl_device = devices ? devices[g] : g;            // thread-local settings of this worker
+            tl_flt_intended = intended; tl_force_generic = generic;
+            rcs[g] = stft_host<T>(fn, Y + lo * W * F, X + lo * ldx, win, hi - lo, N, ldx, L, nfft, stp, snip_edges, mn0, amp, lg);
+        });
+    }
+    for (auto &t : th) { t.join(); }
+    for (int rc : rcs) { if (rc) { return 1; } }
+    return 0;
+}
+
+// device pointers: GPU g holds its block X_dev[g] (signals [lo_g, hi_g) of the batch, dense or with ldx) and its
+// output block Y_dev[g]; if Y_all_dev (memory of devices[0] for the whole [B][W][F]) is given, every block is
+// copied there over the GPU-to-GPU links as soon as it is complete.  Returns when everything has finished.
+template <typename T>
+int stft_multi_dev(const char *fn, T *const *Y_dev, const T *const *X_dev, const T *const *win_dev, T *Y_all_dev, size_t B, size_t N, size_t ldx,
+                   size_t L, size_t nfft, size_t stp, int snip_edges, int mn0, int amp, int lg, const int *devices, int ngpu)
+{
+    FrameDesc d; size_t W;
+    if (stft_desc(fn, d, B, N, ldx, L, nfft, stp, snip_edges, mn0, amp, lg, W)) { return 1; }
+    if (ngpu < 1 || ngpu > MAX_DEV) { fprintf(stderr, "error in %s: ngpu must be in [1 %d]\n", fn, MAX_DEV); return 1; }
+    if (!Y_dev || !X_dev || !win_dev) { fprintf(stderr, "error in %s: null pointer array\n", fn); return 1; }
+    if (W == 0 || B == 0) { return 0; }
+    const size_t F = nfft / 2 + 1;
+    const int dev0 = devices ? devices[0] : 0;
+    const int keep = tl_device;
+    std::vector<hipStream_t> streams(ngpu, nullptr);
+    int rc = 0;
+    for (int g = 0; g < ngpu && !rc; ++g) {
+        size_t lo, hi;
+        shard_range(B, (size_t)g, (size_t)ngpu, lo, hi);
+        if (hi == lo) { continue; }
+        const int dv = devices ? devices[g] : g;
+        tl_device = dv;
+        int cur;
+        if (use_device(fn, cur)) { rc = 1; break; }
+        if (hipStreamCreateWithFlags(&streams[g], hipStreamNonBlocking) != hipSuccess) { fprintf(stderr, "error in %s: hip call failed (stream)\n", fn); rc = 1; break; }
+        rc = stft_dev<T>(fn, Y_dev[g], X_dev[g], win_dev[g], hi - lo, N, ldx, L, nfft, stp, snip_edges, mn0, amp, lg, streams[g]);
+        if (!rc && Y_all_dev && !(dv == dev0 && Y_dev[g] == Y_all_dev + lo * W * F)) {
+            if (hipMemcpyPeerAsync(Y_all_dev + lo * W * F, dev0, Y_dev[g], dv, (hi - lo) * W * F * sizeof(T), streams[g]) != hipSuccess) {
+                fprintf(stderr, "error in %s: hip call failed (copy of a block to device %d)\n", fn, dev0); rc = 1;
+            }
+        }
+    }
+    for (int g = 0; g < ngpu; ++g) {
+        if (!streams[g]) { continue; }
+        (void)hipSetDevice(devices ? devices[g] : g);
+        if (hipStreamSynchronize(streams[g]) != hipSuccess) { fprintf(stderr, "error in %s: hip call failed (synchronize)\n", fn); rc = 1; }
+        (void)hipStreamDestroy(streams[g]);
+    }
+    tl_device = keep;
+    if (keep >= 0) { (void)hipSetDevice(keep); }
     return rc;
 }
 
@@ -1183,6 +1274,22 @@ int dsp_stft_batch_d(double *Y, const double *X, const double *win, const size_t
     if (B > 1 && ldx < N) { fprintf(stderr, "error in dsp_stft_batch_d: ldx must be >= N\n"); return 1; }
     return stft_host<double>("dsp_stft_batch_d", Y, X, win, B, N, ldx, L, nfft, stp, snip_edges, mn0, amp, lg);
 }
+
+void dsp_shard_range(const size_t B, const size_t rank, const size_t world, size_t *lo, size_t *hi)
+{
+    size_t a, b;
+    shard_range(B, rank, world, a, b);
+    if (lo) { *lo = a; }
+    if (hi) { *hi = b; }
+}
+int dsp_stft_multi_s(float *Y, const float *X, const float *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, const int *devices, const int ngpu)
+{ return stft_multi_host<float>("dsp_stft_multi_s", Y, X, win, B, N, ldx, L, nfft, stp, snip_edges, mn0, amp, lg, devices, ngpu); }
+int dsp_stft_multi_d(double *Y, const double *X, const double *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, const int *devices, const int ngpu)
+{ return stft_multi_host<double>("dsp_stft_multi_d", Y, X, win, B, N, ldx, L, nfft, stp, snip_edges, mn0, amp, lg, devices, ngpu); }
+int dsp_stft_multi_dev_s(float *const *Y_dev, const float *const *X_dev, const float *const *win_dev, float *Y_all_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, const int *devices, const int ngpu)
+{ return stft_multi_dev<float>("dsp_stft_multi_dev_s", Y_dev, X_dev, win_dev, Y_all_dev, B, N, ldx, L, nfft, stp, snip_edges, mn0, amp, lg, devices, ngpu); }
+int dsp_stft_multi_dev_d(double *const *Y_dev, const double *const *X_dev, const double *const *win_dev, double *Y_all_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, const int *devices, const int ngpu)
+{ return stft_multi_dev<double>("dsp_stft_multi_dev_d", Y_dev, X_dev, win_dev, Y_all_dev, B, N, ldx, L, nfft, stp, snip_edges, mn0, amp, lg, devices, ngpu); }
 
 int dsp_fft_power_dev_c(float *Y_dev, const float *X_dev, const size_t N, void *stream)
 {

@@ -206,6 +206,22 @@ int dsp_stft_flt_batch_dev_strided_d (double *Y_dev, const double *X_dev, const 
 int dsp_stft_batch_s (float *Y, const float *X, const float *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg);
 int dsp_stft_batch_d (double *Y, const double *X, const double *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg);
 
+/* Several GPUs from one process (the reference is one process, src/stft.cpp:219).  The B signals are split in
+ * contiguous blocks, GPU g of ngpu taking signals [lo, hi) = dsp_shard_range(B, g, ngpu): blocks of
+ * ceil(B / ngpu), the last ones short or empty.  No data crosses between GPUs on the way: every signal is
+ * transformed where it lies.  devices: ngpu device indices, or NULL for 0 .. ngpu-1.
+ * dsp_stft_multi_s/_d: host pointers as dsp_stft_batch_s/_d; every GPU runs its block on a thread of its own
+ * and writes it to its place in Y (the gather is the copy out).
+ * dsp_stft_multi_dev_s/_d: X_dev[g], win_dev[g], Y_dev[g] are GPU g's input block, window and output block
+ * (device memory of devices[g]); Y_all_dev, if not NULL, is memory of devices[0] for the whole Y[B][W][F], and
+ * every block is copied into it over the GPU-to-GPU links as soon as it is complete (a block that already
+ * lies there is not copied).  Both return when all work has finished. */
+void dsp_shard_range (const size_t B, const size_t rank, const size_t world, size_t *lo, size_t *hi);
+int dsp_stft_multi_s (float *Y, const float *X, const float *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, const int *devices, const int ngpu);
+int dsp_stft_multi_d (double *Y, const double *X, const double *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, const int *devices, const int ngpu);
+int dsp_stft_multi_dev_s (float *const *Y_dev, const float *const *X_dev, const float *const *win_dev, float *Y_all_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, const int *devices, const int ngpu);
+int dsp_stft_multi_dev_d (double *const *Y_dev, const double *const *X_dev, const double *const *win_dev, double *Y_all_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, const int *devices, const int ngpu);
+
 /* STFT with the power compression of pow_compress_s/_d fused into the store of every value
  * (power -> [sqrt] -> [log] -> compress): the spectrogram is written once instead of written,
  * re-read and re-written.  Device-pointer and host-pointer batched forms. */

@@ -31,6 +31,19 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in _lib.lib().dsp_stft_version()
 
 
+def test_shard_range_in_the_library_is_the_python_partition():
+    """dsp_shard_range (what the single-process multi-GPU entry points split by) against dsp_amd.dist.shard_range
+    (what the one-process-per-GPU path splits by): the same contiguous blocks, covering the batch exactly."""
+    import dsp_amd
+    from dsp_amd.dist import shard_range
+    for B in (0, 1, 5, 8, 1023, 65536, 65537):
+        for world in (1, 2, 3, 8):
+            spans = [dsp_amd.shard_range(B, r, world) for r in range(world)]
+            assert spans == [shard_range(B, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+    assert dsp_amd.shard_range(65536, 3, 8) == (3 * 8192, 4 * 8192)
+
+
 def test_num_frames_host_logic():
     import dsp_amd
     assert dsp_amd.num_frames(160000, 400, 160, False) == 1000

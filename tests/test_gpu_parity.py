@@ -542,6 +542,30 @@ def test_interleaved_channels_equal_channels_alone(O, D, dt):
         check_spec(O, Y[c].cpu().numpy(), Yref)
 
 
+def test_multi_gpu_entry_points_on_one_device(O, D):
+    """The single-process multi-GPU entry points with every 'GPU' mapped to device 0 (all a one-GPU box allows): the
+    host form (one thread per entry of `devices`, each through the host path for its block) and the device form with
+    the blocks copied into one tensor; both equal the single-GPU result, also for a batch that leaves short and
+    empty blocks."""
+    import torch
+    dt = np.float32
+    win = D.hann(400, dt)
+    wd = torch.from_numpy(win).cuda()
+    for (B, devs) in [(7, [0, 0, 0]), (2, [0, 0, 0, 0]), (5, [0])]:
+        x = np.stack([signal(900 + b, 24000, dt) for b in range(B)])
+        ref = D.stft_batch(x, win, 160, mn0=True)
+        assert np.array_equal(D.stft_multi(x, win, 160, mn0=True, devices=devs), ref)
+        blocks = []
+        for g in range(len(devs)):
+            lo, hi = D.shard_range(B, g, len(devs))
+            blocks.append(torch.from_numpy(x[lo:hi]).cuda().contiguous())
+        ys, y_all = D.stft_multi_dev(blocks, [wd] * len(devs), 160, mn0=True, devices=devs)
+        assert np.array_equal(y_all.cpu().numpy(), ref)
+        assert np.array_equal(torch.cat(ys).cpu().numpy(), ref)
+    rc, Yref = O.stft(x[4], win, 160, 512, 0, 1)
+    check_spec(O, ref[4], Yref)
+
+
 def test_nan_stays_in_its_own_frames(O, D):
     """A NaN sample must only reach the frames that contain it (reflection included)."""
     x = signal(1, 8000, np.float32)

@@ -79,6 +79,9 @@ typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));   // 16-
 #ifndef R4096_RUN
 #define R4096_RUN 32            // frames per run of the run form
 #endif
+#ifndef R4096_NT_STORE
+#define R4096_NT_STORE 0        // 1: rows are stored with the non-temporal hint
+#endif
 #ifndef R4096_STAMPS
 #define R4096_STAMPS 0          // diagnostic builds: 1 = per-phase s_memtime sums into g_r4096_stamps
 #endif
@@ -516,8 +519,13 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
             if (a.N == -12345)
 #endif
             {
+#if R4096_NT_STORE
+                __builtin_nontemporal_store(float4_u{p[0], p[1], p[2], p[3]}, reinterpret_cast<float4_u *>(y + k0));
+                __builtin_nontemporal_store(float4_u{q[3], q[2], q[1], q[0]}, reinterpret_cast<float4_u *>(y + M - 3 - k0));
+#else
                 *reinterpret_cast<float4_u *>(y + k0) = float4_u{p[0], p[1], p[2], p[3]};
                 *reinterpret_cast<float4_u *>(y + M - 3 - k0) = float4_u{q[3], q[2], q[1], q[0]};
+#endif
             }
         }
         {

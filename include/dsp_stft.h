@@ -171,7 +171,14 @@ int dsp_stft_flt_set_mode (const int intended);
 
 /* Batched, DEVICE-resident STFT: B signals of N samples, signal b at X_dev + b*ldx; one window;
  * output Y_dev[b][W][F] dense.  Pointers are device pointers; the work is enqueued on `stream`
- * (a hipStream_t, NULL = default stream) and NOT synchronised.  Flags as stft_s. */
+ * (a hipStream_t, NULL = default stream) and NOT synchronised.  Flags as stft_s.
+ * The first use of an nfft on a device builds its twiddle table (an allocation and a blocking copy; the first use
+ * of a non-integral stft_flt framing likewise builds its table of frame starts); calls after that only enqueue.
+ * Every entry point of this library returns, for a given signal, values that depend on that signal and the
+ * arguments only: the host-pointer, batched, strided, multi-GPU and allocation-free forms give the same bits as
+ * this one.  One exception: nfft 4096 with a full window and hop 1024 walks a signal in runs of 32 frames when the
+ * batch has at least 4096 such runs and frame by frame when it has fewer; the two walks differ in the last bit, so
+ * a signal transformed alone (few runs) and inside a large batch may differ by one ulp. */
 int dsp_stft_batch_dev_s (float *Y_dev, const float *X_dev, const float *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, void *stream);
 int dsp_stft_batch_dev_d (double *Y_dev, const double *X_dev, const double *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, void *stream);
 

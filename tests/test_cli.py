@@ -13,7 +13,7 @@ import pytest
 from conftest import TOL
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BIN = os.path.join(ROOT, "bin")
+BIN = os.path.join(ROOT, os.environ.get("DSP_CLI_BIN", "bin"))      # bin_san: the sanitizer build (make -C cli SAN=1)
 
 
 def run(args, stdin=None, **kw):

@@ -208,6 +208,9 @@ bool r512_fast_supported(const FrameDesc &d);
 bool r4096_supported(const FrameDesc &d);
 // take: 8 counters (32 bytes of device memory) for the run form, or nullptr for the library's own sets
 hipError_t launch_stft_r4096(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, hipStream_t s, unsigned *take = nullptr);
+// nfft 1024 and 2048, float32, equally spaced frames (r512x_kernel.hip)
+bool r512x_supported(const FrameDesc &d);
+hipError_t launch_stft_r512x(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, hipStream_t s);
 template <typename T> bool wave_fft_supported(const FrameDesc &d);
 template <typename T> hipError_t launch_stft_wave(T *Y, const T *X, const T *win, const T *tw, const FrameDesc &d, hipStream_t s);
 template <typename T> hipError_t launch_stft_r512_fast(T *Y, const T *X, const T *win, const T *tw, const FrameDesc &d, hipStream_t s);

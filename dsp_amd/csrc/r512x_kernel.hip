@@ -2,15 +2,17 @@
 // engine of the 512-point kernel (16 lanes, 16 values each: a 16 x 16 four-step transform with one exchange
 // through LDS) under one decimation-in-frequency stage of radix Q = nfft / 512.
 //
-// A frame's nfft reals are M = 256 Q complex points z_n = x_2n + i x_2n+1.  With n = m + 256 g:
-//     Z[Q k + r] = sum_m W256^(m k) * ( W_M^(m r) * sum_g W_Q^(g r) z_(m + 256 g) ),
-// so group r of a frame (16 lanes; Q groups per frame, 4 / Q frames per wavefront and step) reads ALL Q
-// quarters of the windowed frame from the staged span, forms its own combination (signs folded into the
-// window table it reads, the factor (-i)^r and the twiddle W_M^(m r) as per-lane constants) and runs the
-// 256-point transform of that: no exchange between groups on the way in.  On the way out lane (r, j)
-// holds Z[Q (j + 16 k2) + r]; the partner of bin K in the real-FFT split, Z[M - K], lies in group
-// (Q - r) % Q at the mirrored lane: a DPP row move for r = 0 and r = Q / 2, one swap of the wave's halves
-// more for the odd groups of Q = 4.
+// A frame's nfft reals are M = 256 Q complex points z_n = x_2n + i x_2n+1.  With n = m + 256 q:
+//     Z[Q k + r] = sum_m W256^(m k) * ( W_M^(m r) * sum_q W_Q^(q r) z_(m + 256 q) ),
+// i.e. Q independent 256-point transforms, one per residue r of the bin index, each on 16 lanes (a "group";
+// Q groups per frame, 4 / Q frames per wavefront and step).  The radix-Q stage is done where the samples are
+// read: group g reads the rows n1 = Q i + g of the 16 x 16 arrangement m = j + 16 n1 in all Q quarters of the
+// windowed frame (16 LDS reads per lane, window taps in registers), runs the Q-point butterflies of those
+// rows and multiplies by W_M^(m r); then the Q groups trade results with v_permlane16_swap (and
+// v_permlane32_swap for Q = 4) so that each holds ONE residue, r = Q - 1 - g, for all 16 rows.  On the way out
+// lane (r, j) holds Z[Q (j + 16 k2) + r]; the partner of bin K in the real-FFT split, Z[M - K], lies in the
+// group of residue (Q - r) % Q at the mirrored lane: a DPP row move for r = 0 and r = Q / 2, one swap of the
+// wave's halves more for the odd residues of Q = 4.
 //
 // Around the arithmetic, the schedule of the 512-point kernel: one workgroup of 8 waves per CU whose waves
 // draw steps from a counter in LDS; the span of the next step comes by LDS-DMA into a slot of the wave's own
@@ -41,14 +43,8 @@ struct R512XArgs {
 constexpr int R512X_TILE = 4 * R512_EXF * 2;          // floats of a wave's exchange tile / row staging
 constexpr int R512X_WAVES = 8;
 
-#ifndef R512X_DTW_LDS
-#define R512X_DTW_LDS 1         // 1: the twiddles of the radix-Q stage come from an LDS table instead of 32 registers
-#endif
 #ifndef R512X_TWD_LDS
-#define R512X_TWD_LDS 0         // 1: the pass-1 twiddles of the 256-point transform too (30 registers)
-#endif
-#ifndef R512X_CHUNK
-#define R512X_CHUNK 4           // rows of pass 1's input that are read and combined together
+#define R512X_TWD_LDS (Q == 4)  // where the pass-1 twiddles of the 256-point transform come from an LDS table instead of 30 registers (nfft 2048 spills otherwise)
 #endif
 #ifndef R512X_MINIMAL
 #define R512X_MINIMAL 0         // diagnostic builds: 1 = only the plain full-window instantiations
@@ -92,6 +88,23 @@ __device__ __forceinline__ float r512x_xor32(float v, bool low_half)   // lane i
     return __uint_as_float(low_half ? t.y : t.x);
 }
 
+// v_permlane16_swap: the odd rows of 16 lanes of a trade places with the even rows of b;
+// v_permlane32_swap: the upper half of a with the lower half of b
+__device__ __forceinline__ void r512x_swap16(cx<float> &a, cx<float> &b)
+{
+    const r512x_u2 tx = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+    const r512x_u2 ty = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+    a = cx<float>{__uint_as_float(tx.x), __uint_as_float(ty.x)};
+    b = cx<float>{__uint_as_float(tx.y), __uint_as_float(ty.y)};
+}
+__device__ __forceinline__ void r512x_swap32(cx<float> &a, cx<float> &b)
+{
+    const r512x_u2 tx = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+    const r512x_u2 ty = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+    a = cx<float>{__uint_as_float(tx.x), __uint_as_float(ty.x)};
+    b = cx<float>{__uint_as_float(tx.y), __uint_as_float(ty.y)};
+}
+
 template <int Q, bool FULL, bool MN0, bool EPI, int SPAN, bool ALN>
 __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *__restrict__ Y, const float *__restrict__ X,
                                                                          const float *__restrict__ win, const float *__restrict__ tw,
@@ -108,27 +121,19 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = lane >> 4, j = lane & 15;
-    const int f = grp / Q, r = grp % Q;                    // frame of the step, residue of the bins mod Q
+    const int f = grp / Q, g = grp % Q;                    // frame of the step; group inside the frame
+    const int r = Q - 1 - g;                               // residue mod Q of the bins the group ends up with
+    constexpr int R = 16 / Q;                              // rows of the input stage per group
     const int L = a.L;
 
     float *xs = reinterpret_cast<float *>(smem_raw) + wv * WAVE_LDS;   // exchange tile, then row staging
     float2 *ex = reinterpret_cast<float2 *>(xs);
     float *slot = xs + R512X_TILE;                                     // the span
-    float *wtab = reinterpret_cast<float *>(smem_raw) + NWV * WAVE_LDS;   // halved window, signed: [parity of r][NFFT]
-    float2 *dtab = reinterpret_cast<float2 *>(wtab + 2 * NFFT);        // W_M^((j + 16 n1) r) at [r][n1][j]
-    float2 *ttab = dtab + (R512X_DTW_LDS ? 256 * Q : 0);               // W256^(j k1) at [k1][j]
+    float2 *ttab = reinterpret_cast<float2 *>(reinterpret_cast<float *>(smem_raw) + NWV * WAVE_LDS);   // W256^(j k1) at [k1][j]
     float *dummy = reinterpret_cast<float *>(ttab + (R512X_TWD_LDS ? 256 : 0));   // 1 KiB that placeholder LDS-DMA loads write
     unsigned *ticket = reinterpret_cast<unsigned *>(dummy + 256);
 
-    // ---- tables and per-lane constants ----
-    // window table: entry l of copy p is h_l / 2 times the sign group r (parity p) gives quarter g = l / 512:
-    // W_Q^(g r) = (-i)^(g r); its real sign part (-1)^(g r / 2 ...) is folded here for the quarters g >= Q / 2,
-    // i.e. the factor (-1)^r of z_(m + M/2) against z_m
-    for (int l = tid; l < 2 * NFFT; l += 64 * NWV) {
-        const int p = l / NFFT, ll = l - p * NFFT;
-        const float h = (ll < L) ? 0.5f * win[ll] : 0.0f;
-        wtab[l] = (p && ll >= NFFT / 2) ? -h : h;
-    }
+    // ---- per-lane constants ----
     auto twn = [&](int idx) {                              // W_nfft^idx, idx < nfft (the table holds idx < M)
         float sg = 1.0f;
         if (idx >= M) { idx -= M; sg = -1.0f; }
@@ -142,30 +147,30 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
         const C t = twn(2 * Q * (tid & 15) * (tid >> 4));
         ttab[tid] = make_float2(t.x, t.y);
     }
-    C dtw[16];                                             // W_M^((j + 16 n1) r)
-    if constexpr (!R512X_DTW_LDS) {
+    // input stage: row i of the group is n1 = Q i + g, i.e. m = j + 16 n1; halved window taps of its Q quarters
+    // and the twiddles W_M^(m rr), rr = 1 .. Q - 1
+    C hw[16], dt[(Q - 1) * R];
 #pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) { dtw[n1] = twn((2 * (j + 16 * n1) * r) & (NFFT - 1)); }
-    } else {
-        for (int i = tid; i < 256 * Q; i += 64 * NWV) {
-            const C t = twn((2 * (i & 255) * (i >> 8)) & (NFFT - 1));      // [r][m], m = j + 16 n1
-            dtab[i] = make_float2(t.x, t.y);
+    for (int i = 0; i < R; ++i) {
+        const int m = j + 16 * (Q * i + g);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int l = 2 * m + 512 * q;
+            hw[Q * i + q] = C{(l < L) ? 0.5f * win[l] : 0.f, (l + 1 < L) ? 0.5f * win[l + 1] : 0.f};
         }
+#pragma unroll
+        for (int rr = 1; rr < Q; ++rr) { dt[(Q - 1) * i + rr - 1] = twn((2 * m * rr) & (NFFT - 1)); }
     }
-    const float2 *drow = dtab + 256 * r + j;
     C ow[8];                                               // -i W_nfft^K, K = Q (j + 16 k2) + r
 #pragma unroll
     for (int k2 = 0; k2 < 8; ++k2) { const int K = Q * (j + 16 * k2) + r; ow[k2] = C{tw[2 * K + 1], -tw[2 * K]}; }
-    // Q = 4: (-i)^r, the factor of the odd quarters against the even ones
-    const C tq = (r == 0) ? C{1.f, 0.f} : (r == 1) ? C{0.f, -1.f} : (r == 2) ? C{-1.f, 0.f} : C{0.f, 1.f};
     if (tid == 0) { *ticket = NWV; }
     __syncthreads();
 
     const int reach = (FPS - 1) * a.stp;
     const int need = reach + L;                            // samples of a span that pass 1 uses
     const int nvec = (need + 3) / 4;
-    const float *xrow = slot + f * a.stp + 2 * j;
-    const float *wrow = wtab + (r & 1) * NFFT + 2 * j;
+    const float *xrow = slot + f * a.stp + 2 * j + 32 * g;   // row i, quarter q at xrow[32 Q i + 512 q]
 
     // ---- fetch of one span into the slot: NV LDS-DMA loads whatever the case (the counted wait relies on
     // that); a span that crosses an edge of its signal is gathered sample by sample and NV placeholder loads follow
@@ -237,81 +242,73 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
         first_step = false;
         wave_sync();
 
-        // ---- pass 1 input: the lane's combination of the Q quarters, rows n1 of column j ----
+        // ---- input stage: the group's rows in all Q quarters, windowed; Q-point butterflies; twiddles ----
         C zz[16];
-        auto lds2 = [&](const float *p) {
-            if constexpr (ALN) { const float2 t = *reinterpret_cast<const float2 *>(p); return C{t.x, t.y}; }
-            else { const f2e t = *reinterpret_cast<const f2e *>(p); return C{t.x, t.y}; }
-        };
-        auto sample = [&](const int n1, const int g) {
-            C v = lds2(xrow + 32 * n1 + 512 * g);
-            if (!FULL) {
-                const int l = 32 * n1 + 2 * j + 512 * g;
-                v.x = (l < L) ? v.x : 0.f;
-                v.y = (l + 1 < L) ? v.y : 0.f;
-            }
-            return v;
-        };
-        auto tap = [&](const int n1, const int g) {
-            const float2 t = *reinterpret_cast<const float2 *>(wrow + 32 * n1 + 512 * g);
-            return C{t.x, t.y};
-        };
-        auto twiddle_in = [&](const int n1) {
-            if constexpr (R512X_DTW_LDS) { const float2 t = drow[16 * n1]; return C{t.x, t.y}; }
-            else { return dtw[n1]; }
-        };
+        {
+            C A[16];                                       // A[Q i + q]
 #pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) {
-            if constexpr (Q == 2) {
-                zz[n1] = cx_fma(sample(n1, 1), tap(n1, 1), sample(n1, 0) * tap(n1, 0));
-            } else {
-                const C p = cx_fma(sample(n1, 2), tap(n1, 2), sample(n1, 0) * tap(n1, 0));
-                const C q = cx_fma(sample(n1, 3), tap(n1, 3), sample(n1, 1) * tap(n1, 1));
-                // p + (-i)^r q
-                const C t = cx_fma(q, C{tq.x, tq.x}, p);
-                zz[n1] = cx_fma(cx_swap(q), C{-tq.y, tq.y}, t);
-            }
-            if constexpr (!MN0) { zz[n1] = cx_mul<float>(zz[n1], twiddle_in(n1)); }
-            // the rows of a chunk are complete before the reads of the next chunk go out (left alone the
-            // compiler issues the reads of all 16 rows first and runs out of registers)
-            if (n1 % R512X_CHUNK == R512X_CHUNK - 1) {
+            for (int i = 0; i < R; ++i) {
 #pragma unroll
-                for (int i = n1 + 1 - R512X_CHUNK; i <= n1; ++i) { asm volatile("" : "+v"(zz[i]) :: "memory"); }
-            }
-        }
-        if (MN0) {
-            // the mean of the windowed frame is the sum over its group r = 0 (every sign +) divided by L; taken
-            // off every windowed sample inside the window, it changes the lane's combination by mean times the
-            // same combination of the 0/1 masks
-            C acc = zz[0];
-#pragma unroll
-            for (int n1 = 1; n1 < 16; ++n1) { acc += zz[n1]; }
-            float sum = acc.x + acc.y;
-            sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2);
-            sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8);
-            const float mean = __shfl(sum, f * 16 * Q) / (float)L;
-            const float sg = (r & 1) ? -1.f : 1.f;
-#pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) {
-                auto mask = [&](const int g) {
-                    const int l = 32 * n1 + 2 * j + 512 * g;
-                    return C{(FULL || l < L) ? 1.f : 0.f, (FULL || l + 1 < L) ? 1.f : 0.f};
-                };
-                C cm;
-                if constexpr (Q == 2) {
-                    cm = mask(0) + mask(1) * C{sg, sg};
-                } else {
-                    const C p = mask(0) + mask(2) * C{sg, sg};
-                    const C q = mask(1) + mask(3) * C{sg, sg};
-                    const C t = cx_fma(q, C{tq.x, tq.x}, p);
-                    cm = cx_fma(cx_swap(q), C{-tq.y, tq.y}, t);
+                for (int q = 0; q < Q; ++q) {
+                    const float *p = xrow + 32 * Q * i + 512 * q;
+                    C v;
+                    if constexpr (ALN) { const float2 t = *reinterpret_cast<const float2 *>(p); v = C{t.x, t.y}; }
+                    else { const f2e t = *reinterpret_cast<const f2e *>(p); v = C{t.x, t.y}; }
+                    if (!FULL) {                           // keep data past the window out (0 * NaN)
+                        const int l = 2 * j + 32 * (Q * i + g) + 512 * q;
+                        v.x = (l < L) ? v.x : 0.f;
+                        v.y = (l + 1 < L) ? v.y : 0.f;
+                    }
+                    A[Q * i + q] = v * hw[Q * i + q];
                 }
-                zz[n1] -= cm * C{mean, mean};
             }
-        }
-        if constexpr (MN0) {
+            if (MN0) {
+                C acc = A[0];
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) { zz[n1] = cx_mul<float>(zz[n1], twiddle_in(n1)); }
+                for (int i = 1; i < 16; ++i) { acc += A[i]; }
+                float sum = acc.x + acc.y;
+#pragma unroll
+                for (int o = 1; o < 16 * Q; o <<= 1) { sum += __shfl_xor(sum, o); }
+                const float mean = sum / (float)L;
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) {
+                        const int l = 2 * j + 32 * (Q * i + g) + 512 * q;
+                        A[Q * i + q] -= C{(FULL || l < L) ? mean : 0.f, (FULL || l + 1 < L) ? mean : 0.f};
+                    }
+                }
+            }
+            if constexpr (Q == 2) {
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    C o0 = A[2 * i] + A[2 * i + 1];
+                    C o1 = cx_mul<float>(A[2 * i] - A[2 * i + 1], dt[i]);
+                    // the even rows of lanes (g = 0) keep the odd bins of their own rows and get those of the other
+                    // group's rows; the odd rows of lanes the even bins
+                    r512x_swap16(o1, o0);
+                    zz[2 * i] = o1;                        // n1 = 2 i + 0: the row that group 0 read
+                    zz[2 * i + 1] = o0;                    // n1 = 2 i + 1
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    dft4c<float>(A[4 * i], A[4 * i + 1], A[4 * i + 2], A[4 * i + 3]);
+#pragma unroll
+                    for (int rr = 1; rr < 4; ++rr) { A[4 * i + rr] = cx_mul<float>(A[4 * i + rr], dt[3 * i + rr - 1]); }
+                    // neighbouring rows of lanes trade the low bit of the residue ...
+                    r512x_swap16(A[4 * i + 1], A[4 * i + 0]);
+                    r512x_swap16(A[4 * i + 3], A[4 * i + 2]);
+                    // (A[4 i + 2 r1 + 1 - s0] now holds residue bit r1 of the row that the group with low bit s0 read)
+                    // ... and the halves of the wave the high bit
+                    r512x_swap32(A[4 * i + 2], A[4 * i + 0]);
+                    r512x_swap32(A[4 * i + 3], A[4 * i + 1]);
+                    // the first operand of each swap now holds a row read by the lower half (s1 = 0), the second one
+                    // of the upper half: row n1 = 4 i + s, s = 2 s1 + s0, is in A[4 i + 3 - s]
+#pragma unroll
+                    for (int sgrp = 0; sgrp < 4; ++sgrp) { zz[4 * i + sgrp] = A[4 * i + 3 - sgrp]; }
+                }
+            }
         }
         dft16c<float, 16>(zz);
         wave_sync();                                       // all lanes have read the span
@@ -433,7 +430,7 @@ bool r512x_supported(const FrameDesc &d)
 template <int Q, bool FULL, bool MN0, bool EPI, int SPAN, bool ALN>
 static hipError_t launch_r512x_inst(float *Y, const float *X, const float *win, const float *tw, const R512XArgs &a, hipStream_t s)
 {
-    const size_t lds = ((size_t)R512X_WAVES * (R512X_TILE + SPAN) + 2 * 512 * Q + (R512X_DTW_LDS ? 512 * Q : 0) + (R512X_TWD_LDS ? 512 : 0) + 256) * sizeof(float) + 16;
+    const size_t lds = ((size_t)R512X_WAVES * (R512X_TILE + SPAN) + (R512X_TWD_LDS ? 512 : 0) + 256) * sizeof(float) + 16;
     static LdsGrant grant;
     if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r512x_kernel<Q, FULL, MN0, EPI, SPAN, ALN>), lds, grant); e != hipSuccess) { return e; }
     long long grid = ((long long)a.steps + R512X_WAVES - 1) / R512X_WAVES;

@@ -153,6 +153,73 @@ def test_both_power_of_two_families_agree_with_oracle(O, D, dt):
                     check_spec(O, Y, Yref, flags[1], flags[2])
 
 
+def test_1024_2048_kernel_agrees_with_oracle(O, D):
+    """nfft 1024 and 2048 (float32, equally spaced frames) have a kernel of their own (family 6): full, short and
+    odd windows, hops of every alignment up to the span limit and past it (where the family-5 kernel takes over),
+    odd frame counts (a last step with one frame), a signal shorter than the window, every flag, both edge
+    rules, and outputs that start 4, 8 and 12 bytes off a 16-byte boundary."""
+    import torch
+    dt = np.float32
+    assert D.kernel_family(1024, dt) == 6 and D.kernel_family(2048, dt) == 6 and D.kernel_family(1024, np.float64) == 5
+    shapes = [(1024, 1024, 256, (0, 0, 0)), (1024, 1024, 255, (1, 0, 0)), (1024, 800, 200, (0, 1, 0)), (1024, 513, 1024, (1, 1, 1)),
+              (1024, 1000, 1025, (0, 0, 0)), (1024, 3, 77, (1, 0, 1)), (1024, 1024, 1, (0, 0, 0)),
+              (2048, 2048, 512, (0, 0, 0)), (2048, 2047, 441, (1, 0, 0)), (2048, 1200, 300, (0, 1, 1)), (2048, 1025, 5000, (1, 1, 0)),
+              (2048, 2048, 1, (0, 0, 1))]
+    for (nfft, L, stp, flags) in shapes:
+        for N in ((12 * nfft + 77) if stp > 1 else nfft + 300, L // 2 + 1):
+            x = signal(nfft + N + stp, N, dt) + dt(0.15)
+            win = D.povey(L, dt)
+            for snip in (0, 1):
+                if snip and L > N:
+                    continue
+                rc, Yref = O.stft(x.astype(np.float64), win.astype(np.float64), stp, nfft, snip, *flags, exact=False)
+                assert rc == 0
+                Y = D.stft(x, win, stp, bool(snip), *[bool(f) for f in flags], nfft=nfft)
+                check_spec(O, Y, Yref.astype(dt), flags[1], flags[2])
+    # rows that start off 16-byte boundaries, several signals, odd and even frame counts
+    for (nfft, stp, N) in [(1024, 256, 9000), (1024, 300, 9301), (2048, 512, 20000)]:
+        xs = np.stack([signal(10 * k + nfft, N, dt) for k in range(3)])
+        win = D.hann(nfft, dt)
+        want = np.stack([O.stft(r.astype(np.float64), win.astype(np.float64), stp, nfft, 0, exact=False)[1] for r in xs]).astype(dt)
+        xd, wd = torch.from_numpy(xs).cuda(), torch.from_numpy(win).cuda()
+        for off in (0, 1, 2, 3):
+            buf = torch.full((want.size + 8,), 7.0, dtype=torch.float32, device="cuda")
+            out = buf[off:off + want.size].view(want.shape)
+            D.stft_dev(xd, wd, stp, nfft=nfft, out=out)
+            torch.cuda.synchronize()
+            check_spec(O, out.cpu().numpy(), want)
+            assert float(buf[:off].sum()) == 7.0 * off and bool((buf[off + want.size:] == 7.0).all())   # nothing outside the rows
+    # a full grid of workgroups: every launch gives the same bits (the span slots are refilled behind the reads of the
+    # step before), and interior frames do not depend on where a signal lies in the batch
+    for (nfft, stp) in [(1024, 256), (2048, 512)]:
+        xd = torch.randn((64, 1 << 20), device="cuda", generator=torch.Generator(device="cuda").manual_seed(nfft))
+        wd = torch.from_numpy(D.hann(nfft, dt)).cuda()
+        y0 = D.stft_dev(xd, wd, stp, nfft=nfft)
+        ref_sum = int(y0.view(torch.int32).to(torch.int64).sum())
+        y1 = torch.empty_like(y0)
+        for _ in range(10):
+            D.stft_dev(xd, wd, stp, nfft=nfft, out=y1)
+            assert int(y1.view(torch.int32).to(torch.int64).sum()) == ref_sum
+        assert torch.equal(y0, y1)
+        alone = D.stft_dev(xd[37:38].clone(), wd, stp, nfft=nfft)
+        assert torch.equal(alone[0], y0[37])
+        del xd, y0, y1
+    # zero edges and a first frame off the signal (stft_flt with an integral hop); a non-integral hop goes to family 5
+    x = signal(78, 30000, dt)
+    for nfft in (1024, 2048):
+        win = D.blackmanharris(nfft, dt)
+        for intended in (False, True):
+            D.set_flt_mode(intended)
+            try:
+                for (c0, stp, W) in [(0.0, 256.0, 31), (700.0, 300.0, 40), (-1500.0, 512.0, 20), (100.0, 250.5, 20)]:
+                    rc, Yref = O.stft_flt(x.astype(np.float64), win.astype(np.float64), W, c0, stp, nfft, 0, 0, 0, intended=intended, exact=False)
+                    assert rc == 0
+                    Y = D.stft_flt(x, win, W, c0, stp, nfft=nfft)
+                    check_spec(O, Y, Yref.astype(dt))
+            finally:
+                D.set_flt_mode(False)
+
+
 def test_both_4096_families_agree_with_oracle(O, D):
     """nfft 4096 (float32) has a register-resident kernel beside the generic one; each must meet the
     bound on its own: full and short windows, odd hop (unaligned frame starts), a signal shorter

@@ -43,11 +43,13 @@ struct R512FastArgs {
 constexpr int R512F_WAVE_ELEMS = 4 * R512_EXF * 2;   // T elements of a wave's exchange tile (>= 2048: the longest span)
 constexpr int R512F_WAVES = 8;                        // waves per workgroup
 
-// value of lane (16 - i) % 16 of the same 16-lane row (row_mirror, then row_ror:1)
+// value of lane (16 - i) % 16 of the same 16-lane row (row_mirror, then row_ror:1).  Every lane of the row has a
+// source, so the "old" operand is never used: bound_ctrl tells the compiler so (otherwise it zeroes a register
+// in front of every move: 32 more instructions per step)
 __device__ __forceinline__ int dpp_partner16_i(int v)
 {
-    const int m = __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);
-    return __builtin_amdgcn_update_dpp(0, m, 0x121, 0xf, 0xf, false);
+    const int m = __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);
+    return __builtin_amdgcn_update_dpp(0, m, 0x121, 0xf, 0xf, true);
 }
 __device__ __forceinline__ float dpp_partner16(float v) { return __int_as_float(dpp_partner16_i(__float_as_int(v))); }
 __device__ __forceinline__ double dpp_partner16(double v)
@@ -467,14 +469,11 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
 #pragma unroll
         for (int k2 = 0; k2 < 8; ++k2) {
             const C z = zz[slot16(k2)];
-            // (the empty asm keeps the compiler from turning the select of two array elements into a
-            // select of the index, which it would lower to a 16-way chain of conditional moves)
-            T x0 = zz[slot16((16 - k2) & 15)].x, x1 = zz[slot16(15 - k2)].x;
-            T y0 = zz[slot16((16 - k2) & 15)].y, y1 = zz[slot16(15 - k2)].y;
-            asm volatile("" : "+v"(x0), "+v"(x1), "+v"(y0), "+v"(y1));
-            const T sx = (j == 0) ? x0 : x1;
-            const T sy = (j == 0) ? y0 : y1;
-            const C m = C{dpp_partner16(sx), dpp_partner16(sy)};
+            // (lane 0 is its own partner: the move hands it its own register 15 - k2, which the select replaces; a
+            // select in front of the move would be turned into a select of the register INDEX, a 16-way chain)
+            const C own = zz[slot16((16 - k2) & 15)], oth = zz[slot16(15 - k2)];
+            const T px = dpp_partner16(oth.x), py = dpp_partner16(oth.y);
+            const C m = C{(j == 0) ? own.x : px, (j == 0) ? own.y : py};
             const C A = cx_add_conj<T>(z, m), B = cx_sub_conj<T>(z, m);
             const C Tw = cx_mul<T>(B, ow[k2]);
             pw[k2] = cx_norm<T>(A + Tw);

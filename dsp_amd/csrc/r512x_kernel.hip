@@ -75,11 +75,11 @@ __device__ __forceinline__ int r512x_drawn(unsigned &t)
 }
 __device__ __forceinline__ float r512x_mirror(float v)       // lane 15 - i of the same row of 16
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float r512x_ror1(float v)         // lane (i - 1) % 16 of the same row
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, true));
 }
 typedef unsigned r512x_u2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float r512x_xor32(float v, bool low_half)   // lane i ^ 32
@@ -351,12 +351,10 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
 #pragma unroll
         for (int k2 = 0; k2 < 8; ++k2) {
             const C z = zz[slot16(k2)];
-            float x0 = zz[slot16((16 - k2) & 15)].x, x1 = zz[slot16(15 - k2)].x;
-            float y0 = zz[slot16((16 - k2) & 15)].y, y1 = zz[slot16(15 - k2)].y;
-            asm volatile("" : "+v"(x0), "+v"(x1), "+v"(y0), "+v"(y1));   // (keeps the select on the values, not on the index)
-            const float sx = own0 ? x0 : x1;
-            const float sy = own0 ? y0 : y1;
-            const float mx1 = r512x_mirror(sx), my1 = r512x_mirror(sy);
+            // (lane 0 of residue 0 is its own partner: the moves hand it its own register 15 - k2, which the last
+            // select replaces by register (16 - k2) % 16)
+            const C own = zz[slot16((16 - k2) & 15)], oth = zz[slot16(15 - k2)];
+            const float mx1 = r512x_mirror(oth.x), my1 = r512x_mirror(oth.y);
             const float mx2 = r512x_ror1(mx1), my2 = r512x_ror1(my1);
             C m;
             if constexpr (Q == 2) {
@@ -365,6 +363,7 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
                 const float mx3 = r512x_xor32(mx1, lane < 32), my3 = r512x_xor32(my1, lane < 32);
                 m = C{r == 0 ? mx2 : (r == 2 ? mx1 : mx3), r == 0 ? my2 : (r == 2 ? my1 : my3)};
             }
+            m = C{own0 ? own.x : m.x, own0 ? own.y : m.y};
             const C A = cx_add_conj<float>(z, m), B = cx_sub_conj<float>(z, m);
             const C Tw = cx_mul<float>(B, ow[k2]);
             pw[k2] = cx_norm<float>(A + Tw);

@@ -308,7 +308,7 @@ def main():
         "vs_baseline": None, "dtype": "f32" if esz == 4 else "f64", "data": "synthetic",
         "config": {"workload": workload, "signals_per_gpu": B, "samples_per_signal": N, "window": wname, "L": L,
                    "hop": stp, "nfft": nfft, "frames_per_signal": W, "entry_point": "dsp_stft_flt_batch_dev" if kind == "flt" else "dsp_stft_batch_dev",
-                   "kernel_family": "generic" if args.generic else {1: "direct", 2: "pow2", 3: "r512", 4: "r4096", 5: "wave", 6: "r512x"}[dsp_amd.kernel_family(nfft, ndt)],
+                   "kernel_family": "generic" if args.generic else {1: "direct", 2: "pow2", 3: "r512", 4: "r4096", 5: "wave", 6: "r512x", 7: "r256"}[dsp_amd.kernel_family(nfft, ndt)],
                    "sharding": f"{world} ranks x {B} signals, no data-path collective", "device_ramp_ms": args.ramp_ms},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": traffic, "traffic_source": "profiles/traffic.json (separate rocprofv3 --pmc passes)" if traffic else None,

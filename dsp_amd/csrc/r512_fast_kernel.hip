@@ -20,6 +20,7 @@
 //     removes the per-element selects and branches of the general kernel.
 #include "stft_common.h"
 #include "fft16.h"
+#include "span_ring.h"
 #include <cstdlib>
 
 namespace dsp {
@@ -120,35 +121,6 @@ __device__ unsigned long long g_r512f_stamps[8192 * 8];
 #define R512F_MINIMAL 0         // diagnostic builds: 1 = only the benchmark's instantiation is compiled (seconds instead of minutes)
 #endif
 
-// One 16-byte-per-lane LDS-DMA load (1 KiB per wave: lane i's 16 bytes land at lds + 16 i).  Written in
-// assembly so that the compiler's wait counting does not see it (it would wait for ALL outstanding memory
-// operations, the row stores included, before the first read of the span): the kernel waits for a span
-// with a counted s_waitcnt itself.  lds: wave-uniform LDS byte address.
-__device__ __forceinline__ void r512f_glds16(const void *g, const unsigned lds)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(g), "s"(lds) : "memory");
-}
-__device__ __forceinline__ unsigned r512f_lds_addr(const void *p)
-{
-    return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
-}
-template <int N> __device__ __forceinline__ void r512f_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-// Draw of a step: lane 0 alone adds 1 to the workgroup's counter (LDS byte address `cnt`); the old value is in
-// lane 0 of `t` once r512f_drawn has waited for it.  In assembly for the same reason as the load above: the
-// compiler's form waits for the answer on the spot.
-__device__ __forceinline__ void r512f_draw(unsigned &t, const unsigned cnt)
-{
-    unsigned long long keep;
-    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tds_add_rtn_u32 %0, %2, %3\n\ts_mov_b64 exec, %1"
-                 : "=&v"(t), "=&s"(keep) : "v"(cnt), "v"(1u) : "memory");
-}
-__device__ __forceinline__ int r512f_drawn(unsigned &t)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t) :: "memory");
-    return (int)__builtin_amdgcn_readfirstlane(t);
-}
 
 template <typename T, int NR, bool MN0, bool EPI, int WIDE, bool TBL, bool RING>
 __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *__restrict__ Y, const T *__restrict__ X,
@@ -251,9 +223,9 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
                 for (int q = 0; q < NV; ++q) {
                     // only 3*hop + 32*NR samples are ever read by pass 1: lanes past that re-read the last needed vector
 #if R512F_NOLOAD
-                    r512f_glds16(tw + lane * VEC, __builtin_amdgcn_readfirstlane(r512f_lds_addr(dummy)));
+                    ring_glds16(tw + lane * VEC, __builtin_amdgcn_readfirstlane(ring_lds_addr(dummy)));
 #else
-                    r512f_glds16(src + min(q * 64 + lane, nvec - 1) * VEC, __builtin_amdgcn_readfirstlane(r512f_lds_addr(slot + q * 64 * VEC)));
+                    ring_glds16(src + min(q * 64 + lane, nvec - 1) * VEC, __builtin_amdgcn_readfirstlane(ring_lds_addr(slot + q * 64 * VEC)));
 #endif
                 }
             } else {
@@ -264,7 +236,7 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
                     reinterpret_cast<TV *>(slot)[q * 64 + lane] = v;
                 }
 #pragma unroll
-                for (int q = 0; q < NV; ++q) { r512f_glds16(tw + lane * VEC, __builtin_amdgcn_readfirstlane(r512f_lds_addr(dummy))); }
+                for (int q = 0; q < NV; ++q) { ring_glds16(tw + lane * VEC, __builtin_amdgcn_readfirstlane(ring_lds_addr(dummy))); }
             }
         } else if (inside && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
 #pragma unroll
@@ -308,14 +280,14 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
     T *yb = Y + (long long)b * a.W * F;
 
     // the wave's next step, from its latest draw
-    const unsigned cnt_addr = r512f_lds_addr(ticket);
+    const unsigned cnt_addr = ring_lds_addr(ticket);
     unsigned drawn = 0;
     int nsid, nw;
     const T *nxb;
     T *nyb;
     bool more;
     auto advance = [&]() {
-        const int t = r512f_drawn(drawn);
+        const int t = ring_drawn(drawn);
         nsid = first + (t >> 3) * round + (t & 7);
         more = nsid < s_hi;
         if (more) {
@@ -338,7 +310,7 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
     if constexpr (RING) {
         load_span(xb, a.ss0 + w * a.stp);
     } else {
-        r512f_draw(drawn, cnt_addr);
+        ring_draw(drawn, cnt_addr);
         if constexpr (TBL) {
             const int tv = tbl_fetch(w);
             xrow = tbl_xrow(tv);
@@ -358,15 +330,15 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
     // flight.  The stores of a step are unconditional and fixed in number, so the wait for the in-flight span
     // leaves them outstanding instead of draining the store queue.
     while (true) {
-        r512f_draw(drawn, cnt_addr);                       // the step after this one: asked for now, needed further down
+        ring_draw(drawn, cnt_addr);                       // the step after this one: asked for now, needed further down
         if constexpr (RING) {
             // The span of this step was asked for in the middle of the last one.  Memory operations complete in
             // issue order: behind its NV loads lie that step's row stores, so waiting until that many are
             // outstanding leaves the stores in flight.  (First step: nothing lies behind the span.)
             constexpr int K16 = 1028 / VEC / 64 + 1;
-            if (first_step) { r512f_wait_vm<0>(); }
-            else if (a.all16) { r512f_wait_vm<K16>(); }
-            else { r512f_wait_vm<17>(); }
+            if (first_step) { ring_wait_vm<0>(); }
+            else if (a.all16) { ring_wait_vm<K16>(); }
+            else { ring_wait_vm<17>(); }
             first_step = false;
             wave_sync();
             R512F_STAMP(7);
@@ -429,7 +401,7 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
             // first load into the slot is issued: the compiler is free to sink the arithmetic that consumes them (and
             // with it its own wait) below the assembly statements, and a read that is still queued when the first
             // 1 KiB of the new span lands returns the new span's samples (seen as one wrong frame in a million).
-            // r512f_drawn waits for every LDS operation of the wave.  Past the end of the workgroup's share the
+            // ring_drawn waits for every LDS operation of the wave.  Past the end of the workgroup's share the
             // current span is fetched again: the number of loads per step stays fixed.
             advance();
             load_span(more ? nxb : xb, a.ss0 + (more ? nw : w) * a.stp);
@@ -562,7 +534,7 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
     }
     // no LDS-DMA load may land, and no draw return, after the wave has ended (the LDS would belong to another
     // workgroup by then)
-    if constexpr (RING) { r512f_wait_vm<0>(); }
+    if constexpr (RING) { ring_wait_vm<0>(); }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     (void)dummy;
 #if R512F_STAMPS

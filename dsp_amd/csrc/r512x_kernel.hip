@@ -23,6 +23,7 @@
 // stores per step whatever the alignment, which keeps the counted wait for the next span exact.
 #include "stft_common.h"
 #include "fft16.h"
+#include "span_ring.h"
 
 namespace dsp {
 
@@ -50,29 +51,6 @@ constexpr int R512X_WAVES = 8;
 #define R512X_MINIMAL 0         // diagnostic builds: 1 = only the plain full-window instantiations
 #endif
 
-__device__ __forceinline__ void r512x_glds16(const void *g, const unsigned lds)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(g), "s"(lds) : "memory");
-}
-__device__ __forceinline__ unsigned r512x_lds_addr(const void *p)
-{
-    return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
-}
-template <int N> __device__ __forceinline__ void r512x_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-// one lane adds 1 to the workgroup's counter; the old value is in lane 0 of t once r512x_drawn has waited
-__device__ __forceinline__ void r512x_draw(unsigned &t, const unsigned cnt)
-{
-    unsigned long long keep;
-    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tds_add_rtn_u32 %0, %2, %3\n\ts_mov_b64 exec, %1"
-                 : "=&v"(t), "=&s"(keep) : "v"(cnt), "v"(1u) : "memory");
-}
-__device__ __forceinline__ int r512x_drawn(unsigned &t)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t) :: "memory");
-    return (int)__builtin_amdgcn_readfirstlane(t);
-}
 __device__ __forceinline__ float r512x_mirror(float v)       // lane 15 - i of the same row of 16
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));
@@ -181,7 +159,7 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
 #pragma unroll
             for (int q = 0; q < NV; ++q) {
                 // lanes past the last vector that pass 1 uses read that vector again
-                r512x_glds16(src + min(q * 64 + lane, nvec - 1) * 4, __builtin_amdgcn_readfirstlane(r512x_lds_addr(slot + q * 256)));
+                ring_glds16(src + min(q * 64 + lane, nvec - 1) * 4, __builtin_amdgcn_readfirstlane(ring_lds_addr(slot + q * 256)));
             }
         } else {
             FrameDesc d{};
@@ -197,7 +175,7 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
                 reinterpret_cast<float4 *>(slot)[q * 64 + lane] = make_float4(t[0], t[1], t[2], t[3]);
             }
 #pragma unroll
-            for (int q = 0; q < NV; ++q) { r512x_glds16(tw + lane * 4, __builtin_amdgcn_readfirstlane(r512x_lds_addr(dummy))); }
+            for (int q = 0; q < NV; ++q) { ring_glds16(tw + lane * 4, __builtin_amdgcn_readfirstlane(ring_lds_addr(dummy))); }
         }
     };
 
@@ -213,14 +191,14 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
     const float *xb = X + (long long)b * a.ldx;
     float *yb = Y + (long long)b * a.W * F;
 
-    const unsigned cnt_addr = r512x_lds_addr(ticket);
+    const unsigned cnt_addr = ring_lds_addr(ticket);
     unsigned drawn = 0;
     int nsid = 0, nw = 0;
     const float *nxb = xb;
     float *nyb = yb;
     bool more = false;
     auto advance = [&]() {
-        const int t = r512x_drawn(drawn);
+        const int t = ring_drawn(drawn);
         nsid = first + (t >> 3) * round + (t & 7);
         more = nsid < s_hi;
         if (more) {
@@ -235,10 +213,10 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
     load_span(xb, a.ss0 + w * a.stp);
 
     while (true) {
-        r512x_draw(drawn, cnt_addr);                       // the step after this one: asked for now, needed further down
+        ring_draw(drawn, cnt_addr);                       // the step after this one: asked for now, needed further down
         // The span of this step was asked for in the middle of the last one; memory operations complete in issue
         // order and behind its NV loads lie that step's 5 row stores, which stay in flight.
-        if (first_step) { r512x_wait_vm<0>(); } else { r512x_wait_vm<5>(); }
+        if (first_step) { ring_wait_vm<0>(); } else { ring_wait_vm<5>(); }
         first_step = false;
         wave_sync();
 
@@ -314,7 +292,7 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
         wave_sync();                                       // all lanes have read the span
         // The slot takes the next step's span.  The reads of pass 1 must have RETURNED before the first load into
         // the slot is issued (the compiler may sink their consumers, and with them its own wait, below the
-        // assembly statements): r512x_drawn waits for every LDS operation of the wave.  Past the end of the
+        // assembly statements): ring_drawn waits for every LDS operation of the wave.  Past the end of the
         // workgroup's share the current span is fetched again: the number of loads per step stays fixed.
         advance();
         load_span(more ? nxb : xb, a.ss0 + (more ? nw : w) * a.stp);
@@ -411,7 +389,7 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
         sid = nsid; w = nw; xb = nxb; yb = nyb;
     }
     // no LDS-DMA load may land, and no draw return, after the wave has ended
-    r512x_wait_vm<0>();
+    ring_wait_vm<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 

@@ -153,15 +153,18 @@ def test_both_power_of_two_families_agree_with_oracle(O, D, dt):
                     check_spec(O, Y, Yref, flags[1], flags[2])
 
 
-def test_1024_2048_kernel_agrees_with_oracle(O, D):
-    """nfft 1024 and 2048 (float32, equally spaced frames) have a kernel of their own (family 6): full, short and
+def test_256_1024_2048_kernels_agree_with_oracle(O, D):
+    """nfft 256 (family 7), 1024 and 2048 (family 6), float32, equally spaced frames, have kernels of their own: full, short and
     odd windows, hops of every alignment up to the span limit and past it (where the family-5 kernel takes over),
     odd frame counts (a last step with one frame), a signal shorter than the window, every flag, both edge
     rules, and outputs that start 4, 8 and 12 bytes off a 16-byte boundary."""
     import torch
     dt = np.float32
     assert D.kernel_family(1024, dt) == 6 and D.kernel_family(2048, dt) == 6 and D.kernel_family(1024, np.float64) == 5
-    shapes = [(1024, 1024, 256, (0, 0, 0)), (1024, 1024, 255, (1, 0, 0)), (1024, 800, 200, (0, 1, 0)), (1024, 513, 1024, (1, 1, 1)),
+    assert D.kernel_family(256, dt) == 7 and D.kernel_family(256, np.float64) == 5
+    shapes = [(256, 256, 64, (0, 0, 0)), (256, 200, 80, (1, 0, 0)), (256, 255, 33, (0, 1, 0)), (256, 129, 256, (1, 1, 1)), (256, 208, 146, (0, 0, 1)),
+              (256, 193, 257, (0, 0, 0)), (256, 2, 1, (1, 0, 0)),
+              (1024, 1024, 256, (0, 0, 0)), (1024, 1024, 255, (1, 0, 0)), (1024, 800, 200, (0, 1, 0)), (1024, 513, 1024, (1, 1, 1)),
               (1024, 1000, 1025, (0, 0, 0)), (1024, 3, 77, (1, 0, 1)), (1024, 1024, 1, (0, 0, 0)),
               (2048, 2048, 512, (0, 0, 0)), (2048, 2047, 441, (1, 0, 0)), (2048, 1200, 300, (0, 1, 1)), (2048, 1025, 5000, (1, 1, 0)),
               (2048, 2048, 1, (0, 0, 1))]
@@ -177,7 +180,7 @@ def test_1024_2048_kernel_agrees_with_oracle(O, D):
                 Y = D.stft(x, win, stp, bool(snip), *[bool(f) for f in flags], nfft=nfft)
                 check_spec(O, Y, Yref.astype(dt), flags[1], flags[2])
     # rows that start off 16-byte boundaries, several signals, odd and even frame counts
-    for (nfft, stp, N) in [(1024, 256, 9000), (1024, 300, 9301), (2048, 512, 20000)]:
+    for (nfft, stp, N) in [(256, 80, 5000), (256, 64, 4157), (1024, 256, 9000), (1024, 300, 9301), (2048, 512, 20000)]:
         xs = np.stack([signal(10 * k + nfft, N, dt) for k in range(3)])
         win = D.hann(nfft, dt)
         want = np.stack([O.stft(r.astype(np.float64), win.astype(np.float64), stp, nfft, 0, exact=False)[1] for r in xs]).astype(dt)
@@ -191,7 +194,7 @@ def test_1024_2048_kernel_agrees_with_oracle(O, D):
             assert float(buf[:off].sum()) == 7.0 * off and bool((buf[off + want.size:] == 7.0).all())   # nothing outside the rows
     # a full grid of workgroups: every launch gives the same bits (the span slots are refilled behind the reads of the
     # step before), and interior frames do not depend on where a signal lies in the batch
-    for (nfft, stp) in [(1024, 256), (2048, 512)]:
+    for (nfft, stp) in [(256, 80), (1024, 256), (2048, 512)]:
         xd = torch.randn((64, 1 << 20), device="cuda", generator=torch.Generator(device="cuda").manual_seed(nfft))
         wd = torch.from_numpy(D.hann(nfft, dt)).cuda()
         y0 = D.stft_dev(xd, wd, stp, nfft=nfft)
@@ -206,7 +209,7 @@ def test_1024_2048_kernel_agrees_with_oracle(O, D):
         del xd, y0, y1
     # zero edges and a first frame off the signal (stft_flt with an integral hop); a non-integral hop goes to family 5
     x = signal(78, 30000, dt)
-    for nfft in (1024, 2048):
+    for nfft in (256, 1024, 2048):
         win = D.blackmanharris(nfft, dt)
         for intended in (False, True):
             D.set_flt_mode(intended)

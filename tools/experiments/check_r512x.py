@@ -1,4 +1,4 @@
-"""nfft 1024 / 2048 float32 kernel: results against the generic kernel family on the same device (which the parity
+"""nfft 256 / 1024 / 2048 float32 kernels: results against the generic kernel family on the same device (which the parity
 tests pin to the oracle), launch-to-launch equality, and launch time against the LDS-pass kernel it replaces
 (DSP_R512X_OFF=1 in the environment selects that one)."""
 import sys
@@ -27,9 +27,9 @@ def one(nfft, L, hop, B, N, snip, mn0, amp, lg, seed):
 
 bad = 0
 cases = []
-for nfft in (1024, 2048):
-    for L in (nfft, nfft - 24, nfft // 2 + 3, 7):
-        for hop in (nfft // 4, nfft // 2, 160, 161, 441, nfft, 1):
+for nfft in (256, 1024, 2048):
+    for L in (nfft, nfft - 24, nfft - 56, nfft // 2 + 3, 7):
+        for hop in (nfft // 4, nfft // 2, 80, 160, 161, 441, nfft, 1):
             for snip in (1, 0):
                 cases.append((nfft, L, hop, snip))
 rng = np.random.default_rng(5)
@@ -61,7 +61,7 @@ def timeit(nfft, L, hop, B, N):
     return ms, byts / ms / 8e9 * 100
 
 if bad == 0 or '--time' in sys.argv:
-    for nfft, L, hop in ((1024, 1024, 256), (1024, 1024, 512), (1024, 800, 200), (1024, 1024, 128), (2048, 2048, 512), (2048, 2048, 1024), (2048, 1200, 300)):
+    for nfft, L, hop in ((256, 256, 64), (256, 200, 80), (256, 256, 128), (256, 256, 33), (1024, 1024, 256), (1024, 1024, 512), (1024, 800, 200), (1024, 1024, 128), (2048, 2048, 512), (2048, 2048, 1024), (2048, 1200, 300)):
         ms, pct = timeit(nfft, L, hop, 8, 1 << 25)
         print(f'time nfft {nfft} L {L} hop {hop}: {ms:.3f} ms  {pct:.1f} % of 8 TB/s', flush=True)
 sys.exit(1 if bad else 0)

@@ -42,6 +42,10 @@ WORKLOADS = {
     "utt1x10s_f32_hann400_hop160_nfft512": ("float32", 1, 160000, "hann", 400, 160, 512, "stft"),
     "flt_f64_8ch_x_1h16k_povey400_hop160_nfft512": ("float64", 8, 57600000, "povey", 400, 160, 512, "flt"),
     "longwin_f32_8ch_x_1h48k_bh4096_hop1024_nfft4096": ("float32", 8, 172800000, "blackmanharris", 4096, 1024, 4096, "stft"),
+    # the other transform lengths with kernels of their own (not configurations of BASELINE.json)
+    "tel1024x10s8k_f32_hann200_hop80_nfft256": ("float32", 1024, 80000, "hann", 200, 80, 256, "stft"),
+    "music64x60s44k_f32_hann1024_hop256_nfft1024": ("float32", 64, 2646000, "hann", 1024, 256, 1024, "stft"),
+    "music64x60s44k_f32_hann2048_hop512_nfft2048": ("float32", 64, 2646000, "hann", 2048, 512, 2048, "stft"),
 }
 DEFAULT_1GPU = "utt1024x10s_f32_hann400_hop160_nfft512"
 DEFAULT_NGPU = "utt8192x10s_f32_hann400_hop160_nfft512"

@@ -47,6 +47,12 @@ constexpr int R512X_WAVES = 8;
 #ifndef R512X_TWD_LDS
 #define R512X_TWD_LDS (Q == 4 || SPAN == 2048)   // where the pass-1 twiddles of the 256-point transform come from an LDS table instead of 30 registers (these instantiations spill otherwise; measured: 1024 / hop 512 0.480 -> 0.449 ms, and 6 % slower where nothing spills)
 #endif
+#ifndef R512X_NOLOAD
+#define R512X_NOLOAD 0          // diagnostic builds: 1 = the span loads fetch the twiddle table instead (no HBM reads)
+#endif
+#ifndef R512X_NOSTORE
+#define R512X_NOSTORE 0         // diagnostic builds: 1 = the row stores are compiled out
+#endif
 #ifndef R512X_MINIMAL
 #define R512X_MINIMAL 0         // diagnostic builds: 1 = only the plain full-window instantiations
 #endif
@@ -159,7 +165,11 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
 #pragma unroll
             for (int q = 0; q < NV; ++q) {
                 // lanes past the last vector that pass 1 uses read that vector again
+#if R512X_NOLOAD
+                ring_glds16(tw + lane * 4, __builtin_amdgcn_readfirstlane(ring_lds_addr(slot + q * 256)));
+#else
                 ring_glds16(src + min(q * 64 + lane, nvec - 1) * 4, __builtin_amdgcn_readfirstlane(ring_lds_addr(slot + q * 256)));
+#endif
             }
         } else {
             FrameDesc d{};
@@ -377,6 +387,10 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
             for (int i = 0; i < 4; ++i) {
                 const int v = min(lane + 64 * i, nb - 1);
                 const f4nt val = *reinterpret_cast<const f4nt *>(xs + sh + head + 4 * v);
+#if R512X_NOSTORE
+                asm volatile("" :: "v"(val));
+                if (a.N == -12345)
+#endif
                 __builtin_nontemporal_store(val, reinterpret_cast<f4nt *>(yblk + head + 4 * v));
             }
             int e = nout - 1;

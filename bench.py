@@ -33,7 +33,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak
-FP32_VALU_PEAK_TFLOPS = 157.3   # MI355X FP32 vector peak
+FP32_VALU_PEAK_TFLOPS = 157.3   # MI355X FP32 vector peak: 256 CUs x 4 SIMDs x 64 flops per cycle x 2.4 GHz
+# what a loop of nothing but packed fmas sustains (tools/experiments/ubench/clock_cal.hip: the shader clock settles at
+# 1.975 GHz under that load, 4 cycles per packed wave instruction)
+FP32_VALU_SUSTAINED_TFLOPS = 129.4
 
 WORKLOADS = {
     # name: (dtype, B per GPU, N, window, L, hop, nfft, kind)
@@ -321,7 +324,8 @@ def main():
     if esz == 4:
         # the other bound of this path: float32 vector issue, on the nominal 5 N log2 N flops (nfft 4096 sits on the ridge)
         out["roofline_valu"] = {"bound": "fp32_valu", "achieved": tflops, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": tflops / FP32_VALU_PEAK_TFLOPS}
+                                "frac": tflops / FP32_VALU_PEAK_TFLOPS, "sustained_peak": FP32_VALU_SUSTAINED_TFLOPS,
+                                "sustained_frac": tflops / FP32_VALU_SUSTAINED_TFLOPS}
     if gather is not None:
         out["gather"] = gather
     if rank == 0 and world == 1 and B == 1:

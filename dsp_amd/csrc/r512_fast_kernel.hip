@@ -42,7 +42,10 @@ struct R512FastArgs {
 };
 
 constexpr int R512F_WAVE_ELEMS = 4 * R512_EXF * 2;   // T elements of a wave's exchange tile (>= 2048: the longest span)
-constexpr int R512F_WAVES = 8;                        // waves per workgroup
+#ifndef R512F_NWAVES
+#define R512F_NWAVES 8          // waves per workgroup (4 to 8; a workgroup's round is 8 steps whatever their number)
+#endif
+constexpr int R512F_WAVES = R512F_NWAVES;
 
 // value of lane (16 - i) % 16 of the same 16-lane row (row_mirror, then row_ror:1).  Every lane of the row has a
 // source, so the "old" operand is never used: bound_ctrl tells the compiler so (otherwise it zeroes a register
@@ -133,7 +136,6 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
     // WIDE 2: 32 (2048: hop <= 512)
     constexpr int VEC = vec16<T>::n, SPAN = WIDE == 2 ? 2048 : WIDE ? 1280 : 1024, NV = SPAN / 64 / VEC;
     static_assert(SPAN <= R512F_WAVE_ELEMS, "the staged span lives in the wave's exchange region");
-    static_assert(!RING || !TBL, "the LDS-DMA form takes equally spaced frames");
     constexpr int WAVE_LDS = R512F_WAVE_ELEMS + (RING ? SPAN : 0);
     constexpr bool WINREG = (sizeof(T) == 4) && !R512F_WIN_LDS;
     // pass-1 twiddles in registers, except where they do not fit beside the other state (double; spans of 2048
@@ -196,6 +198,18 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
     // table form: lane i holds the start of frame w + (i & 3) of a step (clamped to the last frame)
     auto tbl_fetch = [&](const int w_) { return a.tbl[2 * min(w_ + (lane & 3), a.W - 1)]; };
     auto tbl_xrow = [&](const int tv) { return xs + (__shfl(tv, f) - __builtin_amdgcn_readfirstlane(tv)) + 2 * j; };
+
+    // RING, table form: the starts of the 4 frames of the step at frame w_ (wave-uniform) by scalar loads -- a vector
+    // load would put the compiler's own wait for ALL outstanding memory operations, the row stores included, in
+    // front of the span fetch.  Sets xrow for that step and returns the start of its span.
+    auto tbl_step = [&](const int w_) {
+        const __attribute__((address_space(4))) int *tp = (const __attribute__((address_space(4))) int *)(uintptr_t)a.tbl;
+        const int last = a.W - 1;
+        const int t0 = tp[2 * w_], t1 = tp[2 * min(w_ + 1, last)], t2 = tp[2 * min(w_ + 2, last)], t3 = tp[2 * min(w_ + 3, last)];
+        const int off = (f == 0) ? 0 : (f == 1) ? t1 - t0 : (f == 2) ? t2 - t0 : t3 - t0;
+        xrow = slot + off + 2 * j;
+        return t0;
+    };
 
     // ---- fetch of one span (frames w..w+3 of the signal at xb): into registers, or (RING) into the slot.
     // A span that crosses an edge of its signal (reflection or zeros) is gathered sample by sample.
@@ -271,8 +285,8 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
     // its round t / 8: the wave that is ready first takes it.
     const int xcd = blockIdx.x & 7, nwg_x = gridDim.x >> 3;
     const int s_lo = (int)((long long)a.steps * xcd / 8), s_hi = (int)((long long)a.steps * (xcd + 1) / 8);
-    const int round = nwg_x * NWV, first = s_lo + (blockIdx.x >> 3) * NWV;
-    int sid = first + wv;
+    const int round = nwg_x * 8, first = s_lo + (blockIdx.x >> 3) * 8;
+    int sid = first + (wv >> 3) * round + (wv & 7);      // draw number wv
     if (sid >= s_hi) { return; }
     int b = sid / a.sps;
     int w = (sid - b * a.sps) * 4;
@@ -308,7 +322,8 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
     int tvn = 0;
     bool first_step = true;
     if constexpr (RING) {
-        load_span(xb, a.ss0 + w * a.stp);
+        if constexpr (TBL) { load_span(xb, tbl_step(w)); }
+        else { load_span(xb, a.ss0 + w * a.stp); }
     } else {
         ring_draw(drawn, cnt_addr);
         if constexpr (TBL) {
@@ -391,7 +406,7 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
         }
         dft16c<T, NR>(zz);
         const T *nxrow = xrow;
-        if constexpr (TBL) {
+        if constexpr (TBL && !RING) {
             if (more) { nxrow = tbl_xrow(tvn); load_span(nxb, __builtin_amdgcn_readfirstlane(tvn)); }
         }
         R512F_STAMP(0);
@@ -404,7 +419,8 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
             // ring_drawn waits for every LDS operation of the wave.  Past the end of the workgroup's share the
             // current span is fetched again: the number of loads per step stays fixed.
             advance();
-            load_span(more ? nxb : xb, a.ss0 + (more ? nw : w) * a.stp);
+            if constexpr (TBL) { load_span(more ? nxb : xb, tbl_step(more ? nw : w)); }      // (pass 1 is done with xrow)
+            else { load_span(more ? nxb : xb, a.ss0 + (more ? nw : w) * a.stp); }
         }
         {
             T2 *exf = ex + f * R512_EXF + j;
@@ -569,7 +585,7 @@ static hipError_t launch_fast_inst(T *Y, const T *X, const T *win, const T *tw, 
     const size_t lds = (R512F_WAVES * ((size_t)R512F_WAVE_ELEMS + (RING ? SPAN : 0)) + 512 + 512) * sizeof(T) + 1024 + 16;
     static LdsGrant grant;
     if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r512_fast_kernel<T, NR, MN0, EPI, WIDE, TBL, RING>), lds, grant); e != hipSuccess) { return e; }
-    long long grid = ((long long)a.steps + R512F_WAVES - 1) / R512F_WAVES;
+    long long grid = ((long long)a.steps + 7) / 8;
     if (grid > 256) { grid = 256; }                     // one 8-wave workgroup per CU
     grid = (grid + 7) & ~7ll;                           // whole groups of 8 workgroups (one per XCD)
     hipLaunchKernelGGL((stft_r512_fast_kernel<T, NR, MN0, EPI, WIDE, TBL, RING>), dim3((unsigned)grid), dim3(64 * R512F_WAVES), lds, s, Y, X, win, tw, a);
@@ -595,8 +611,11 @@ hipError_t launch_stft_r512_fast(T *Y, const T *X, const T *win, const T *tw, co
 #define DSP_R512F(NR_, MN0_, EPI_) launch_fast_inst<T, NR_, MN0_, EPI_, 0, false, RING>(Y, X, win, tw, a, s)
 #define DSP_R512W(MN0_, EPI_) launch_fast_inst<T, 16, MN0_, EPI_, 1, false, RING>(Y, X, win, tw, a, s)
 #define DSP_R512X(MN0_, EPI_) launch_fast_inst<T, 16, MN0_, EPI_, 2, false, RING>(Y, X, win, tw, a, s)
+// table form: spans of up to 1280 samples through registers (by LDS-DMA they measured 44.5 % of the HBM peak against
+// 50.1 %: the frames of such a table start at odd and even offsets alike, the unaligned LDS reads of pass 1 bound
+// it, and the DMA form spills), longer ones by LDS-DMA (61.0 % against 59.3 %)
 #define DSP_R512T(MN0_, EPI_) launch_fast_inst<T, 16, MN0_, EPI_, 1, true, false>(Y, X, win, tw, a, s)
-#define DSP_R512U(MN0_, EPI_) launch_fast_inst<T, 16, MN0_, EPI_, 2, true, false>(Y, X, win, tw, a, s)
+#define DSP_R512U(MN0_, EPI_) launch_fast_inst<T, 16, MN0_, EPI_, 2, true, RING>(Y, X, win, tw, a, s)
 #if R512F_MINIMAL
     if constexpr (sizeof(T) == 4) { if (nr13 && !d.mn0 && !epi && !d.tbl) { return DSP_R512F(13, false, false); } }
     return hipErrorInvalidValue;

@@ -120,6 +120,36 @@ def cpu_baseline(x_host, win, stp, nfft, kind, W, budget_s=10.0):
         dt = time.perf_counter() - t0
         return sum(done) * W / dt, sum(done), dt
 
+    def reference_chain(budget):
+        """The same spectrogram by the reference's OWN code where that builds without FFTW (oracle/_ref/libdspref.so,
+        compiled from the reference's sources where they lie): c/window_univar(_flt).c -> c/fft.rad2.c (complex entry
+        point, rows padded to nfft) -> c/fft_power.c, one thread.  Not what its stft runs (that is FFTW's r2c), so it is
+        reported beside the port, not instead of it."""
+        try:
+            from oracle import oracle as O
+            if O.ref() is None:
+                return None
+            t0 = time.perf_counter()
+            n = 0
+            while n == 0 or time.perf_counter() - t0 < budget:
+                xs = x_host[n % nb]
+                if kind == "flt":
+                    rc, fr = O.ref_window_univar_flt(xs, win, W, float(L // 2), float(stp))
+                else:
+                    rc, fr = O.ref_window_univar(xs, win, stp, False)
+                assert rc == 0
+                for lo in range(0, fr.shape[0], 4096):          # bounded temporaries
+                    rc, sp = O.ref_fft_rad2(fr[lo:lo + 4096], nfft)
+                    assert rc == 0
+                    rc, _ = O.ref_fft_power(sp)
+                    assert rc == 0
+                n += 1
+            dt = time.perf_counter() - t0
+            return {"value": n * W / dt, "unit": "frames/s", "cores": 1, "kind": "reference",
+                    "sample": f"{n} signal(s), {n * W} frames, {dt:.1f} s: window_univar -> fft_rad2 (complex, padded rows) -> fft_power from the reference's sources; the padding copy is numpy's"}
+        except Exception as e:  # the checker's helper library is optional on the box
+            return {"error": repr(e)[:200]}
+
     cores = host_cores()
     v1, n1, t1 = leg(1)
     vall, nall, tall = leg(cores) if cores > 1 else (v1, n1, t1)
@@ -130,6 +160,7 @@ def cpu_baseline(x_host, win, stp, nfft, kind, W, budget_s=10.0):
         "all_cores": {"value": vall, "unit": "frames/s", "cores": cores,
                       "sample": f"{nall} signal transforms, one signal per thread at a time ({nall * W} frames, {tall:.1f} s)"},
         "host": {"cores_usable": cores, "cpu_count": os.cpu_count(), "fft": fftw_note},
+        "reference_chain": reference_chain(min(5.0, budget_s)),
     }
 
 

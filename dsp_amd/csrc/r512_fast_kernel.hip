@@ -190,7 +190,7 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
     }
     if (tid == 0) { *ticket = NWV; }                         // the first 8 steps go to the waves in order
     __syncthreads();
-    static_assert(!TBL || (WIDE >= 1 && NR == 16), "the table form uses the wide, 16-row instantiations");
+    static_assert(!TBL || WIDE >= 1, "the table form uses the wide instantiations");
     const int reach = TBL ? a.stp : 3 * a.stp;               // start of the step's last frame relative to its first
     const int need = reach + 512;
     const int nvec = (reach + 32 * NR + VEC - 1) / VEC;      // 16-byte vectors of a span that pass 1 reads
@@ -607,14 +607,14 @@ hipError_t launch_stft_r512_fast(T *Y, const T *X, const T *win, const T *tw, co
     // float, equally spaced frames: spans by LDS-DMA (the double kernel's exchange tiles leave no LDS for span slots)
     constexpr bool RING = sizeof(T) == 4 && R512F_RING_F32;
     const bool wide = 3 * d.stp + 512 > 1024 || (d.stp & 1);   // spans of more than 1024 samples (20 staged elements per lane), odd hops
-    const bool nr13 = d.L > 384 && d.L <= 416 && !wide;
+    const bool nr13 = d.L > 384 && d.L <= 416;               // windows that leave the last three rows of pass 1 empty (400: 25 ms at 16 kHz)
 #define DSP_R512F(NR_, MN0_, EPI_) launch_fast_inst<T, NR_, MN0_, EPI_, 0, false, RING>(Y, X, win, tw, a, s)
-#define DSP_R512W(MN0_, EPI_) launch_fast_inst<T, 16, MN0_, EPI_, 1, false, RING>(Y, X, win, tw, a, s)
+#define DSP_R512W(NR_, MN0_, EPI_) launch_fast_inst<T, NR_, MN0_, EPI_, 1, false, RING>(Y, X, win, tw, a, s)
 #define DSP_R512X(MN0_, EPI_) launch_fast_inst<T, 16, MN0_, EPI_, 2, false, RING>(Y, X, win, tw, a, s)
 // table form: spans of up to 1280 samples through registers (by LDS-DMA they measured 44.5 % of the HBM peak against
 // 50.1 %: the frames of such a table start at odd and even offsets alike, the unaligned LDS reads of pass 1 bound
 // it, and the DMA form spills), longer ones by LDS-DMA (61.0 % against 59.3 %)
-#define DSP_R512T(MN0_, EPI_) launch_fast_inst<T, 16, MN0_, EPI_, 1, true, false>(Y, X, win, tw, a, s)
+#define DSP_R512T(NR_, MN0_, EPI_) launch_fast_inst<T, NR_, MN0_, EPI_, 1, true, false>(Y, X, win, tw, a, s)
 #define DSP_R512U(MN0_, EPI_) launch_fast_inst<T, 16, MN0_, EPI_, 2, true, RING>(Y, X, win, tw, a, s)
 #if R512F_MINIMAL
     if constexpr (sizeof(T) == 4) { if (nr13 && !d.mn0 && !epi && !d.tbl) { return DSP_R512F(13, false, false); } }
@@ -624,17 +624,25 @@ hipError_t launch_stft_r512_fast(T *Y, const T *X, const T *win, const T *tw, co
         if (d.mn0) { return epi ? DSP_R512U(true, true) : DSP_R512U(true, false); }
         return epi ? DSP_R512U(false, true) : DSP_R512U(false, false);
     }
+    if (d.tbl && nr13) {
+        if (d.mn0) { return epi ? DSP_R512T(13, true, true) : DSP_R512T(13, true, false); }
+        return epi ? DSP_R512T(13, false, true) : DSP_R512T(13, false, false);
+    }
     if (d.tbl) {
-        if (d.mn0) { return epi ? DSP_R512T(true, true) : DSP_R512T(true, false); }
-        return epi ? DSP_R512T(false, true) : DSP_R512T(false, false);
+        if (d.mn0) { return epi ? DSP_R512T(16, true, true) : DSP_R512T(16, true, false); }
+        return epi ? DSP_R512T(16, false, true) : DSP_R512T(16, false, false);
     }
     if (3 * d.stp + 512 > 1280) {
         if (d.mn0) { return epi ? DSP_R512X(true, true) : DSP_R512X(true, false); }
         return epi ? DSP_R512X(false, true) : DSP_R512X(false, false);
     }
+    if (wide && nr13) {
+        if (d.mn0) { return epi ? DSP_R512W(13, true, true) : DSP_R512W(13, true, false); }
+        return epi ? DSP_R512W(13, false, true) : DSP_R512W(13, false, false);
+    }
     if (wide) {
-        if (d.mn0) { return epi ? DSP_R512W(true, true) : DSP_R512W(true, false); }
-        return epi ? DSP_R512W(false, true) : DSP_R512W(false, false);
+        if (d.mn0) { return epi ? DSP_R512W(16, true, true) : DSP_R512W(16, true, false); }
+        return epi ? DSP_R512W(16, false, true) : DSP_R512W(16, false, false);
     }
     if (nr13) {
         if (d.mn0) { return epi ? DSP_R512F(13, true, true) : DSP_R512F(13, true, false); }

@@ -184,6 +184,21 @@ def config1_extras(dsp_amd, x, win_h, stp, nfft):
         torch.cuda.synchronize()
     dev_us = (time.perf_counter() - t0) / 200 * 1e6
     out = {"stft_s_host_pointers_us_per_call": host_us, "stft_batch_dev_plus_sync_us_per_call": dev_us}
+    # the kernel alone, warm (its 1.7 MB working set never leaves the caches) and cold (512 MB written between launches)
+    scrub = torch.empty(128 << 20, dtype=torch.float32, device=x.device)
+    for name, cold in (("kernel_us_warm", False), ("kernel_us_cold", True)):
+        ts = []
+        for i in range(30):
+            if cold:
+                scrub.fill_(float(i))
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            dsp_amd.stft_dev(x, win, stp, out=y)
+            b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b) * 1e3)
+        out[name] = {"median": float(np.median(ts)), "min": float(np.min(ts))}
+    del scrub
     tool = os.path.join(ROOT, "bin", "stft")
     if os.path.exists(tool):
         with tempfile.TemporaryDirectory() as d:
@@ -264,10 +279,12 @@ def main():
     F = nfft // 2 + 1
     win_h = dsp_amd.WINDOWS[wname](L, ndt)
     win = torch.from_numpy(win_h).to(dev)
-    # synthetic signals generated on the owning GPU; seed depends on the global signal block
-    g = torch.Generator(device=dev).manual_seed(0xD5F0 + rank)
+    # synthetic signals generated on the owning GPU, a seed per block of 64 signals of the WHOLE job: a signal's samples
+    # do not depend on the number of GPUs the job is cut over
+    g = torch.Generator(device=dev)
     x = torch.empty((B, N), dtype=tdt, device=dev)
     for b0 in range(0, B, 64):
+        g.manual_seed(0xD5F0 + (rank * B + b0) // 64)
         x[b0:b0 + 64] = torch.randn((min(64, B - b0), N), generator=g, device=dev, dtype=tdt) * 0.1
     if kind == "flt":
         W = (N - 1 - L // 2) // stp
@@ -310,7 +327,8 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    kern_all = [a.elapsed_time(b) for a, b in ev]
+    kern_ms = float(np.mean(kern_all))
 
     gather = None
     if world > 1 and not args.no_gather and kind == "stft":
@@ -350,7 +368,8 @@ def main():
                    "sharding": f"{world} ranks x {B} signals, no data-path collective", "device_ramp_ms": args.ramp_ms},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": traffic, "traffic_source": "profiles/traffic.json (separate rocprofv3 --pmc passes)" if traffic else None,
-                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms, "nominal_tflops_5NlogN": tflops},
+                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms, "kernel_ms_median": float(np.median(kern_all)), "kernel_ms_min": float(np.min(kern_all)),
+                     "nominal_tflops_5NlogN": tflops},
     }
     if esz == 4:
         # the other bound of this path: float32 vector issue, on the nominal 5 N log2 N flops (nfft 4096 sits on the ridge)

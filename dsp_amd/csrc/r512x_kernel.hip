@@ -97,7 +97,6 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
     static_assert(Q == 2 || Q == 4, "nfft 1024 or 2048");
     using C = cx<float>;
     typedef float f2e __attribute__((ext_vector_type(2), aligned(4)));
-    typedef float f4nt __attribute__((ext_vector_type(4)));
     constexpr int NFFT = 512 * Q, M = 256 * Q, F = M + 1, FPS = 4 / Q, NWV = R512X_WAVES, NV = SPAN / 256;
     constexpr int WAVE_LDS = R512X_TILE + SPAN;
     static_assert(FPS * F + 3 <= R512X_TILE, "row staging fits the tile");
@@ -153,40 +152,17 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
 
     const int reach = (FPS - 1) * a.stp;
     const int need = reach + L;                            // samples of a span that pass 1 uses
-    const int nvec = (need + 3) / 4;
     const float *xrow = slot + f * a.stp + 2 * j + 32 * g;   // row i, quarter q at xrow[32 Q i + 512 q]
 
     // ---- fetch of one span into the slot: NV LDS-DMA loads whatever the case (the counted wait relies on
     // that); a span that crosses an edge of its signal is gathered sample by sample and NV placeholder loads follow
     auto load_span = [&](const float *xb, const int s0) {
-        const float *src = xb + (s0 - (a.edge ? a.rd_shift : 0));
-        const bool inside = s0 >= 0 && s0 + 4 * nvec <= a.N && (a.edge == 0 || s0 >= a.rd_shift);
-        if (inside) {
-#pragma unroll
-            for (int q = 0; q < NV; ++q) {
-                // lanes past the last vector that pass 1 uses read that vector again
-#if R512X_NOLOAD
-                ring_glds16(tw + lane * 4, __builtin_amdgcn_readfirstlane(ring_lds_addr(slot + q * 256)));
-#else
-                ring_glds16(src + min(q * 64 + lane, nvec - 1) * 4, __builtin_amdgcn_readfirstlane(ring_lds_addr(slot + q * 256)));
-#endif
-            }
-        } else {
-            FrameDesc d{};
-            d.N = a.N; d.edge = a.edge;
-#pragma clang loop unroll(disable)
-            for (int q = 0; q < NV; ++q) {
-                float t[4];
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int i = (q * 64 + lane) * 4 + v;
-                    t[v] = (i < need) ? fetch_sample(xb, d, (long long)s0, (long long)a.rd_shift, i) : 0.f;
-                }
-                reinterpret_cast<float4 *>(slot)[q * 64 + lane] = make_float4(t[0], t[1], t[2], t[3]);
-            }
-#pragma unroll
-            for (int q = 0; q < NV; ++q) { ring_glds16(tw + lane * 4, __builtin_amdgcn_readfirstlane(ring_lds_addr(dummy))); }
-        }
+        ring_load_span<NV>(slot, dummy, tw, R512X_NOLOAD ? tw - (s0 - (a.edge ? a.rd_shift : 0)) : xb, s0, need, a.N, a.edge, a.rd_shift, lane,
+                           [&](const float *sig, const int first, const int i) {
+                               FrameDesc d{};
+                               d.N = a.N; d.edge = a.edge;
+                               return fetch_sample(sig, d, (long long)first, (long long)a.rd_shift, i);
+                           });
     };
 
     // Work distribution: 8 contiguous ranges of steps, one per group of workgroups that share an XCD; a round
@@ -364,8 +340,8 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
         // the step's block of rows in the output, and how it lies against 16-byte boundaries
         float *yblk = yb + (size_t)w * F;
         const int nout = __builtin_amdgcn_readfirstlane(min(FPS, a.W - w) * F);
-        const int head = __builtin_amdgcn_readfirstlane((int)(((16u - ((unsigned)reinterpret_cast<uintptr_t>(yblk) & 15u)) & 15u) >> 2));
-        const int sh = (4 - head) & 3;                     // value e of the block is staged at xs[sh + e]
+        const int head = ring_block_head(yblk);
+        const int sh = ring_stage_shift(head);             // value e of the block is staged at xs[sh + e]
         wave_sync();                                       // every lane has read its tile row: reuse the region
         {
             float *pf = xs + sh + f * F;
@@ -381,23 +357,7 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
 
         // ---- five stores: four of whole 16-byte vectors, one for the values before and after them.  Surplus
         // lanes repeat a valid store (same value to the same address).
-        {
-            const int nb = (nout - head) >> 2, tail = nout - head - 4 * nb;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int v = min(lane + 64 * i, nb - 1);
-                const f4nt val = *reinterpret_cast<const f4nt *>(xs + sh + head + 4 * v);
-#if R512X_NOSTORE
-                asm volatile("" :: "v"(val));
-                if (a.N == -12345)
-#endif
-                __builtin_nontemporal_store(val, reinterpret_cast<f4nt *>(yblk + head + 4 * v));
-            }
-            int e = nout - 1;
-            if (lane < head) { e = lane; }
-            else if (lane >= 4 && lane - 4 < tail) { e = head + 4 * nb + lane - 4; }
-            __builtin_nontemporal_store(xs[sh + e], yblk + e);
-        }
+        ring_store_rows<4, R512X_NOSTORE != 0>(yblk, xs + sh, head, nout, lane);
         if (!more) { break; }
         wave_sync();                                       // staging reads are done before the next step writes the tile
         sid = nsid; w = nw; xb = nxb; yb = nyb;

@@ -2,6 +2,7 @@
 // (r512_fast_kernel.hip, r512x_kernel.hip, r256_kernel.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdint>
 
 namespace dsp {
 
@@ -34,6 +35,69 @@ __device__ __forceinline__ int ring_drawn(unsigned &t)
 {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t) :: "memory");
     return (int)__builtin_amdgcn_readfirstlane(t);
+}
+
+// ---- rows of a step, staged in LDS in output order, to memory at any 4-byte alignment --------------------------
+// How a block of `nout` floats at `yblk` lies against 16-byte boundaries: `head` floats (0 to 3) come before the
+// first boundary.  The kernels stage value e of the block at stage[e], stage = tile + ring_stage_shift(head), which
+// puts the 16-byte boundaries of the OUTPUT on 16-byte boundaries of the LDS.
+__device__ __forceinline__ int ring_block_head(const float *yblk)
+{
+    return __builtin_amdgcn_readfirstlane((int)(((16u - ((unsigned)reinterpret_cast<uintptr_t>(yblk) & 15u)) & 15u) >> 2));
+}
+__device__ __forceinline__ int ring_stage_shift(const int head) { return (4 - head) & 3; }
+// NVI wave stores of whole 16-byte vectors (NVI * 256 >= nout) and one more for the values before and after
+// them: NVI + 1 store instructions whatever nout and the alignment, which keeps a counted vmcnt wait exact.
+// Surplus lanes repeat a valid store (same value to the same address).  SKIP: diagnostic builds without the stores.
+template <int NVI, bool SKIP = false>
+__device__ __forceinline__ void ring_store_rows(float *__restrict__ yblk, const float *stage, const int head, const int nout, const int lane)
+{
+    typedef float f4nt __attribute__((ext_vector_type(4)));
+    const int nb = (nout - head) >> 2, tail = nout - head - 4 * nb;
+#pragma unroll
+    for (int i = 0; i < NVI; ++i) {
+        const int v = min(lane + 64 * i, nb - 1);
+        const f4nt val = *reinterpret_cast<const f4nt *>(stage + head + 4 * v);
+        if constexpr (SKIP) { asm volatile("" :: "v"(val)); }
+        else { __builtin_nontemporal_store(val, reinterpret_cast<f4nt *>(yblk + head + 4 * v)); }
+    }
+    int e = nout - 1;
+    if (lane < head) { e = lane; }
+    else if (lane >= 4 && lane - 4 < tail) { e = head + 4 * nb + lane - 4; }
+    if constexpr (!SKIP) { __builtin_nontemporal_store(stage[e], yblk + e); }
+}
+
+// ---- one span into a wave's slot: NV LDS-DMA loads whatever the case (a counted wait relies on that) -----------
+// Samples s0 .. s0 + need of the signal at xb (read at s0 - rd_shift under the zero-edge rule).  Inside the signal:
+// NV wave loads of 1 KiB, lanes past the last vector that is used (nvec = ceil(need / 4)) read that vector again.
+// A span that crosses an edge of its signal is gathered sample by sample (reflection or zeros) and NV placeholder
+// loads follow, from the first KiB of `tw` into `dummy`.
+template <int NV, typename FETCH>
+__device__ __forceinline__ void ring_load_span(float *slot, float *dummy, const float *tw, const float *xb, const int s0, const int need,
+                                               const int N, const int edge, const int rd_shift, const int lane, FETCH fetch)
+{
+    const int nvec = (need + 3) / 4;
+    const float *src = xb + (s0 - (edge ? rd_shift : 0));
+    const bool inside = s0 >= 0 && s0 + 4 * nvec <= N && (edge == 0 || s0 >= rd_shift);
+    if (inside) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            ring_glds16(src + min(q * 64 + lane, nvec - 1) * 4, __builtin_amdgcn_readfirstlane(ring_lds_addr(slot + q * 256)));
+        }
+    } else {
+#pragma clang loop unroll(disable)
+        for (int q = 0; q < NV; ++q) {
+            float t[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int i = (q * 64 + lane) * 4 + v;
+                t[v] = (i < need) ? fetch(xb, s0, i) : 0.f;
+            }
+            reinterpret_cast<float4 *>(slot)[q * 64 + lane] = make_float4(t[0], t[1], t[2], t[3]);
+        }
+#pragma unroll
+        for (int q = 0; q < NV; ++q) { ring_glds16(tw + lane * 4, __builtin_amdgcn_readfirstlane(ring_lds_addr(dummy))); }
+    }
 }
 
 }  // namespace dsp

@@ -76,6 +76,10 @@ typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));   // 16-
 #ifndef R4096_ALT_PRIO
 #define R4096_ALT_PRIO 0
 #endif
+#ifndef R4096_PHASE_PRIO
+#define R4096_PHASE_PRIO 0      // bit 0: raised priority from the twiddle stage to the reads of pass 2, bit 1: from the Z writes to the end of the split's reads, bit 2: during the window step
+#endif
+#define R4096_PRIO(bit, v) do { if (R4096_PHASE_PRIO & (bit)) { __builtin_amdgcn_s_setprio(v); } } while (0)
 #ifndef R4096_RUN
 #define R4096_RUN 32            // frames per run of the run form
 #endif
@@ -329,6 +333,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         }
 #endif
         // ---------------- pass 1: window, 32-point FFT over n1 ----------------
+        R4096_PRIO(4, 1);
         {
             C2 acc = C2{0.f, 0.f};
             int lim = L - loff;                              // sample l = 256 i + loff + c is inside the window iff 256 i + c < lim
@@ -370,6 +375,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
             for (int i = 0; i < 16; ++i) { asm volatile("" : "+v"(ze[i]), "+v"(zo[i])); }
         }
         R4096_STAMP(6);
+        R4096_PRIO(4, 0);
         // RUN: the stream moves on by one group, whose loads go out now, into the registers of the
         // group that the next frame no longer holds
         if constexpr (RUN) {
@@ -397,6 +403,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
             zo[s] = E - t;
         }
         R4096_STAMP(0);
+        R4096_PRIO(1, 1);
 
         // twiddle W2048^(n2 k1), k1 = 4 q + b
 #if R4096_INTERLEAVE
@@ -472,8 +479,10 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
 #pragma unroll
             for (int m = 0; m < 16; ++m) { ze[m] = row[m]; zo[m] = row[16 + m]; }   // even / odd columns
         }
+        R4096_PRIO(1, 0);
         dft32c(ze, zo);
         R4096_STAMP(2);
+        R4096_PRIO(2, 1);
         wave_sync();                                       // every lane has its row: the tile becomes Z
         {
             C2 *zdst = ex + zpos((lane >> 1) + 32 * (lane & 1));   // Z[k1 + 32 parity + 64 k']
@@ -542,6 +551,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
             y[1024] = p;
         }
         R4096_STAMP(5);
+        R4096_PRIO(2, 0);
         if constexpr (RUN) {
             if (tpos + 1 >= run_len) { return false; }
             ++tpos;

@@ -229,7 +229,7 @@ int flt_desc(const char *fn, int dev, FrameDesc &d, size_t B, size_t N, size_t l
             const size_t w3 = (w + 3 < W) ? w + 3 : W - 1;
             reach = std::max(reach, (long long)tbl[2 * w3] - tbl[2 * w]);
         }
-        f.tbl_reach = (reach >= 0 && reach <= 1536) ? (int)reach : -1;
+        f.tbl_reach = (reach >= 0 && reach <= (1 << 30)) ? (int)reach : -1;   // (each kernel family has its own bound on it)
         // (first use of a framing: an allocation and a blocking copy; repeated calls find it in the cache)
         int *p = nullptr;
         HIPCHK(fn, hipMalloc((void **)&p, tbl.size() * sizeof(int)));

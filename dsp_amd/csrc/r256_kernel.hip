@@ -31,6 +31,8 @@ struct R256Args {
     Epilogue epi;
     int sps;              // steps (groups of 8 consecutive frames) per signal
     int steps;            // B * sps
+    const int *tbl;       // table form: start of frame w at tbl[2 w] (frames need not be equally spaced); else nullptr
+    int reach;            // table form: bound on the distance between the starts of the first and last frame of a step
 };
 
 constexpr int R256_FP = 152;                         // complex slots per frame in the exchange tile (16 rows, pitch 9, + 8)
@@ -115,9 +117,26 @@ __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__
     if (tid == 0) { *ticket = NWV; }
     __syncthreads();
 
-    const int reach = (FPS - 1) * a.stp;
+    const int reach = a.tbl ? a.reach : (FPS - 1) * a.stp;
     const int need = reach + min(L, 16 * NR);              // samples of a span that pass 1 uses
     const float *xrow = slot + f * a.stp + 2 * j;
+    // Start of the span of the step at frame w_ (wave-uniform).  Table form: the starts of the step's 8 frames by
+    // scalar loads (a vector load would put the compiler's own wait for ALL outstanding memory operations, the row
+    // stores included, in front of the span fetch), and xrow for that step: called when pass 1 is done with the last one.
+    auto step_start = [&](const int w_) {
+        if (a.tbl == nullptr) { return a.ss0 + w_ * a.stp; }
+        const __attribute__((address_space(4))) int *tp = (const __attribute__((address_space(4))) int *)(uintptr_t)a.tbl;
+        const int last = a.W - 1;
+        const int t0 = tp[2 * w_];
+        int off = 0;
+#pragma unroll
+        for (int i = 1; i < FPS; ++i) {
+            const int ti = tp[2 * min(w_ + i, last)];
+            off = (f == i) ? ti - t0 : off;
+        }
+        xrow = slot + off + 2 * j;
+        return t0;
+    };
 
     // ---- fetch of one span into the slot: NV LDS-DMA loads whatever the case (the counted wait relies on
     // that); a span that crosses an edge of its signal is gathered sample by sample and NV placeholder loads follow
@@ -161,7 +180,7 @@ __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__
     };
 
     bool first_step = true;
-    load_span(xb, a.ss0 + w * a.stp);
+    load_span(xb, step_start(w));
 
     while (true) {
         ring_draw(drawn, cnt_addr);                        // the step after this one: asked for now, needed further down
@@ -213,7 +232,7 @@ __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__
         // assembly statements): ring_drawn waits for every LDS operation of the wave.  Past the end of the
         // workgroup's share the current span is fetched again: the number of loads per step stays fixed.
         advance();
-        load_span(more ? nxb : xb, a.ss0 + (more ? nw : w) * a.stp);
+        load_span(more ? nxb : xb, step_start(more ? nw : w));
         {
             float2 *exf = ex + f * R256_FP + j;
 #pragma unroll
@@ -303,11 +322,13 @@ __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-// nfft 256, frames at ss0 + w * hop with the 8 frames of a step inside 2048 samples, and every index of one
-// signal's input and output inside 31 bits
+// nfft 256; frames at ss0 + w * hop, or a table of frame starts that never decrease and are read where they start;
+// the 8 frames of a step inside 2048 samples; every index of one signal's input and output inside 31 bits
 bool r256_supported(const FrameDesc &d)
 {
-    return d.nfft == 256 && d.tbl == nullptr && d.stp >= 1 && 7ll * d.stp + 256 <= 2048 && d.L >= 1 && d.L <= 256 &&
+    // (tbl_reach bounds the distance of frames w and w + 3: three times that bounds the distance of frames w and w + 7)
+    const bool placed = d.tbl ? (d.tbl_reach >= 0 && 3ll * d.tbl_reach + 256 <= 2048) : (d.stp >= 1 && 7ll * d.stp + 256 <= 2048);
+    return d.nfft == 256 && placed && d.L >= 1 && d.L <= 256 &&
            d.N < (1ll << 31) - 4096 && (long long)d.W * 129 < (1ll << 30) && (long long)d.B * d.W < (1ll << 30) &&
            d.ss0 > -(1ll << 30) && d.ss0 < (1ll << 30) && d.rd_shift >= 0 && d.rd_shift < (1ll << 30);
 }
@@ -345,6 +366,11 @@ hipError_t launch_stft_r256(float *Y, const float *X, const float *win, const fl
     a.rd_shift = (int)d.rd_shift; a.edge = d.edge; a.epi = d.epi;
     a.sps = (d.W + 7) / 8;
     a.steps = d.B * a.sps;
+    a.tbl = d.tbl; a.reach = 0;
+    if (d.tbl) {
+        a.stp = 0; a.ss0 = 0; a.rd_shift = 0; a.reach = 3 * d.tbl_reach;
+        return launch_r256_shape<16, 2048, false>(Y, X, win, tw, a, d, s);
+    }
     const int reach = 7 * d.stp + 256;
     // windows of 193 to 208 samples (200: 25 ms at 8 kHz) leave the last three rows of pass 1 empty
     const bool nr13 = d.L > 192 && d.L <= 208;

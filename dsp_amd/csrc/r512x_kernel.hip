@@ -39,6 +39,8 @@ struct R512XArgs {
     Epilogue epi;
     int sps;              // steps per signal
     int steps;            // B * sps
+    const int *tbl;       // table form: start of frame w at tbl[2 w] (frames need not be equally spaced); else nullptr
+    int reach;            // table form: bound on the distance between the starts of the first and last frame of a step
 };
 
 constexpr int R512X_TILE = 4 * R512_EXF * 2;          // floats of a wave's exchange tile / row staging
@@ -150,9 +152,22 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
     if (tid == 0) { *ticket = NWV; }
     __syncthreads();
 
-    const int reach = (FPS - 1) * a.stp;
+    const int reach = a.tbl ? a.reach : (FPS - 1) * a.stp;
     const int need = reach + L;                            // samples of a span that pass 1 uses
     const float *xrow = slot + f * a.stp + 2 * j + 32 * g;   // row i, quarter q at xrow[32 Q i + 512 q]
+    // Start of the span of the step at frame w_ (wave-uniform).  Table form: the starts of the step's frames by
+    // scalar loads (a vector load would put the compiler's own wait for ALL outstanding memory operations, the row
+    // stores included, in front of the span fetch), and xrow for that step: called when pass 1 is done with the last one.
+    auto step_start = [&](const int w_) {
+        if (a.tbl == nullptr) { return a.ss0 + w_ * a.stp; }
+        const __attribute__((address_space(4))) int *tp = (const __attribute__((address_space(4))) int *)(uintptr_t)a.tbl;
+        const int t0 = tp[2 * w_];
+        if constexpr (FPS == 2) {
+            const int t1 = tp[2 * min(w_ + 1, a.W - 1)];
+            xrow = slot + (f ? t1 - t0 : 0) + 2 * j + 32 * g;
+        }
+        return t0;
+    };
 
     // ---- fetch of one span into the slot: NV LDS-DMA loads whatever the case (the counted wait relies on
     // that); a span that crosses an edge of its signal is gathered sample by sample and NV placeholder loads follow
@@ -196,7 +211,7 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
     };
 
     bool first_step = true;
-    load_span(xb, a.ss0 + w * a.stp);
+    load_span(xb, step_start(w));
 
     while (true) {
         ring_draw(drawn, cnt_addr);                       // the step after this one: asked for now, needed further down
@@ -281,7 +296,7 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
         // assembly statements): ring_drawn waits for every LDS operation of the wave.  Past the end of the
         // workgroup's share the current span is fetched again: the number of loads per step stays fixed.
         advance();
-        load_span(more ? nxb : xb, a.ss0 + (more ? nw : w) * a.stp);
+        load_span(more ? nxb : xb, step_start(more ? nw : w));
         {
             float2 *exf = ex + grp * R512_EXF + j;
 #pragma unroll
@@ -367,13 +382,16 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-// nfft 1024 or 2048, frames at ss0 + w * hop with the frames of a step inside 2048 samples, and every index
-// of one signal's input and output inside 31 bits
+// nfft 1024 or 2048; frames at ss0 + w * hop, or a table of frame starts that never decrease and are read where they
+// start; the frames of a step inside 2048 samples; every index of one signal's input and output inside 31 bits
 bool r512x_supported(const FrameDesc &d)
 {
     if (d.nfft != 1024 && d.nfft != 2048) { return false; }
     const int fps = 4 / (d.nfft / 512);
-    return d.tbl == nullptr && d.stp >= 1 && (long long)(fps - 1) * d.stp + d.nfft <= 2048 && d.L >= 1 && d.L <= d.nfft &&
+    // (tbl_reach bounds the distance of frames w and w + 3, hence that of the fps <= 2 frames of a step)
+    const bool placed = d.tbl ? (d.tbl_reach >= 0 && (fps == 1 || d.tbl_reach + d.nfft <= 2048))
+                              : (d.stp >= 1 && (long long)(fps - 1) * d.stp + d.nfft <= 2048);
+    return placed && d.L >= 1 && d.L <= d.nfft &&
            d.N < (1ll << 31) - 4096 && (long long)d.W * (d.nfft / 2 + 1) < (1ll << 30) && (long long)d.B * d.W < (1ll << 30) &&
            d.ss0 > -(1ll << 30) && d.ss0 < (1ll << 30) && d.rd_shift >= 0 && d.rd_shift < (1ll << 30);
 }
@@ -418,8 +436,10 @@ hipError_t launch_stft_r512x(float *Y, const float *X, const float *win, const f
     a.rd_shift = (int)d.rd_shift; a.edge = d.edge; a.epi = d.epi;
     a.sps = (d.W + fps - 1) / fps;
     a.steps = d.B * a.sps;
+    a.tbl = d.tbl; a.reach = 0;
+    if (d.tbl) { a.stp = 0; a.ss0 = 0; a.rd_shift = 0; a.reach = (fps == 1) ? 0 : d.tbl_reach; }
     if (Q == 4) { return launch_r512x_shape<4, 2048, true>(Y, X, win, tw, a, d, s); }
-    if (d.stp & 1) { return launch_r512x_shape<2, 2048, false>(Y, X, win, tw, a, d, s); }
+    if (d.tbl || (d.stp & 1)) { return launch_r512x_shape<2, 2048, false>(Y, X, win, tw, a, d, s); }
     if (d.stp + 1024 <= 1280) { return launch_r512x_shape<2, 1280, true>(Y, X, win, tw, a, d, s); }
     return launch_r512x_shape<2, 2048, true>(Y, X, win, tw, a, d, s);
 }

@@ -259,8 +259,8 @@ int dsp_fft_power_dev_z (double *Y_dev, const double *X_dev, const size_t N, voi
  * 0 = none (invalid), 1 = direct DFT (nfft not a power of two), 2 = generic power-of-two,
  * 3 = register-resident 512-point, 4 = register-resident 4096-point (float32), 5 = the other powers of two from 16
  * to 8192 (float32) / 4096 (float64), 6 = 1024- and 2048-point (float32), 7 = 256-point (float32).  Families 6 and 7
- * take equally spaced frames whose hop keeps the frames of a step (2, 1 and 8 frames) inside 2048 samples; other
- * framings of those lengths run on family 5.  For tests and benchmarks. */
+ * take frames (equally spaced, or the stft_flt framing of any hop) that keep a step (2, 1 and 8 frames) inside 2048
+ * samples; other framings of those lengths run on family 5.  For tests and benchmarks. */
 int dsp_stft_kernel_family (const size_t nfft, const size_t elem_size);
 
 /* Forces the generic kernel family (2, or 1 for non-powers-of-two) when on != 0; for A/B tests. */

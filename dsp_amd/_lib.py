@@ -68,6 +68,18 @@ SIGNATURES = {
     "gauss_s": (_int, [_vp, _sz, _f, _sz]), "gauss_d": (_int, [_vp, _sz, _d, _sz]),
     "tukey_s": (_int, [_vp, _sz, _f, _sz]), "tukey_d": (_int, [_vp, _sz, _d, _sz]),
     "planck_s": (_int, [_vp, _sz, _f, _sz]), "planck_d": (_int, [_vp, _sz, _d, _sz]),
+    "hann_c": (_int, [_vp, _sz, _sz]), "hann_z": (_int, [_vp, _sz, _sz]),
+    "hamming_c": (_int, [_vp, _sz, _sz]), "hamming_z": (_int, [_vp, _sz, _sz]),
+    "povey_c": (_int, [_vp, _sz, _sz]), "povey_z": (_int, [_vp, _sz, _sz]),
+    "blackmanharris_c": (_int, [_vp, _sz, _sz]), "blackmanharris_z": (_int, [_vp, _sz, _sz]),
+    "bartlett_c": (_int, [_vp, _sz, _sz]), "bartlett_z": (_int, [_vp, _sz, _sz]),
+    "triangular_c": (_int, [_vp, _sz, _sz]), "triangular_z": (_int, [_vp, _sz, _sz]),
+    "rectangular_c": (_int, [_vp, _sz, _sz]), "rectangular_z": (_int, [_vp, _sz, _sz]),
+    "flattop_c": (_int, [_vp, _sz, _sz]), "flattop_z": (_int, [_vp, _sz, _sz]),
+    "blackman_c": (_int, [_vp, _sz, _int, _sz]), "blackman_z": (_int, [_vp, _sz, _int, _sz]),
+    "gauss_c": (_int, [_vp, _sz, _f, _sz]), "gauss_z": (_int, [_vp, _sz, _d, _sz]),
+    "tukey_c": (_int, [_vp, _sz, _f, _sz]), "tukey_z": (_int, [_vp, _sz, _d, _sz]),
+    "planck_c": (_int, [_vp, _sz, _f, _sz]), "planck_z": (_int, [_vp, _sz, _d, _sz]),
     "convert_freqs_s": (_int, [_vp, _sz, C.c_char_p, C.c_char_p]), "convert_freqs_d": (_int, [_vp, _sz, C.c_char_p, C.c_char_p]),
     "pow_compress_s": (_int, [_vp, _vp, _sz, _f, _f]), "pow_compress_d": (_int, [_vp, _vp, _sz, _d, _d]),
     "pow_compress_inplace_s": (_int, [_vp, _sz, _f, _f]), "pow_compress_inplace_d": (_int, [_vp, _sz, _d, _d]),

@@ -304,11 +304,11 @@ WINDOW_PAR = {"gauss": 2.5, "tukey": 0.5, "planck": 0.1}        # generators wit
 
 
 def window(name, L, norm=0, dtype=np.float32, par=None, exact=False):
-    """hann_s/_d ... planck_s/_d: the window computed by the library.  par: gauss a, tukey r, planck
+    """hann_s/_d/_c/_z ... planck_s/_d/_c/_z: the window computed by the library.  par: gauss a, tukey r, planck
     epsilon; exact: blackman's exact coefficients."""
     if name not in WINDOW_IDS:
         raise ValueError(f"unknown window {name}")
-    s = _real_sfx(np.dtype(dtype))
+    s = _any_sfx(np.dtype(dtype))               # complex dtypes: the _c/_z forms (zero imaginary parts)
     Y = np.empty(L, dtype=dtype)
     fn = getattr(lib(), f"{name}_{s}")
     if name in WINDOW_PAR:

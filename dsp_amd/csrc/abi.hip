@@ -840,6 +840,18 @@ int window_host(const char *fn, T *Y, size_t L, size_t norm, int kind, T par = T
     return 0;
 }
 
+// the complex forms (reference c/hann.c:67-113 and the like): the same L values, each followed by a zero imaginary part
+template <typename T>
+int window_host_cplx(const char *fn, T *Y, size_t L, size_t norm, int kind, T par = T(0), int flag = 0)
+{
+    if (L > (size_t)INT_MAX / 4) { fprintf(stderr, "error in %s: problem size exceeds the supported index range\n", fn); return 1; }
+    std::vector<T> w;
+    try { w.resize(L); } catch (const std::exception &) { fprintf(stderr, "error in %s: problem with malloc. \n", fn); return 1; }
+    if (int rc = window_host<T>(fn, w.data(), L, norm, kind, par, flag)) { return rc; }
+    for (size_t l = 0; l < L; ++l) { Y[2 * l] = w[l]; Y[2 * l + 1] = T(0); }
+    return 0;
+}
+
 template <typename T>
 int window_dev(const char *fn, T *Yd, int kind, size_t L, size_t norm, void *stream, T par = T(0), int flag = 0)
 {
@@ -1128,6 +1140,30 @@ int tukey_s(float *Y, const size_t L, const float r, const size_t norm) { return
 int tukey_d(double *Y, const size_t L, const double r, const size_t norm) { return window_host<double>("tukey_d", Y, L, norm, WIN_TUKEY, r); }
 int planck_s(float *Y, const size_t L, const float epsilon, const size_t norm) { return window_host<float>("planck_s", Y, L, norm, WIN_PLANCK, epsilon); }
 int planck_d(double *Y, const size_t L, const double epsilon, const size_t norm) { return window_host<double>("planck_d", Y, L, norm, WIN_PLANCK, epsilon); }
+int hann_c(float *Y, const size_t L, const size_t norm) { return window_host_cplx<float>("hann_c", Y, L, norm, 0); }
+int hann_z(double *Y, const size_t L, const size_t norm) { return window_host_cplx<double>("hann_z", Y, L, norm, 0); }
+int hamming_c(float *Y, const size_t L, const size_t norm) { return window_host_cplx<float>("hamming_c", Y, L, norm, 1); }
+int hamming_z(double *Y, const size_t L, const size_t norm) { return window_host_cplx<double>("hamming_z", Y, L, norm, 1); }
+int povey_c(float *Y, const size_t L, const size_t norm) { return window_host_cplx<float>("povey_c", Y, L, norm, 2); }
+int povey_z(double *Y, const size_t L, const size_t norm) { return window_host_cplx<double>("povey_z", Y, L, norm, 2); }
+int blackmanharris_c(float *Y, const size_t L, const size_t norm) { return window_host_cplx<float>("blackmanharris_c", Y, L, norm, 3); }
+int blackmanharris_z(double *Y, const size_t L, const size_t norm) { return window_host_cplx<double>("blackmanharris_z", Y, L, norm, 3); }
+int bartlett_c(float *Y, const size_t L, const size_t norm) { return window_host_cplx<float>("bartlett_c", Y, L, norm, WIN_BARTLETT); }
+int bartlett_z(double *Y, const size_t L, const size_t norm) { return window_host_cplx<double>("bartlett_z", Y, L, norm, WIN_BARTLETT); }
+int triangular_c(float *Y, const size_t L, const size_t norm) { return window_host_cplx<float>("triangular_c", Y, L, norm, WIN_TRIANGULAR); }
+int triangular_z(double *Y, const size_t L, const size_t norm) { return window_host_cplx<double>("triangular_z", Y, L, norm, WIN_TRIANGULAR); }
+int rectangular_c(float *Y, const size_t L, const size_t norm) { return window_host_cplx<float>("rectangular_c", Y, L, norm, WIN_RECTANGULAR); }
+int rectangular_z(double *Y, const size_t L, const size_t norm) { return window_host_cplx<double>("rectangular_z", Y, L, norm, WIN_RECTANGULAR); }
+int flattop_c(float *Y, const size_t L, const size_t norm) { return window_host_cplx<float>("flattop_c", Y, L, norm, WIN_FLATTOP); }
+int flattop_z(double *Y, const size_t L, const size_t norm) { return window_host_cplx<double>("flattop_z", Y, L, norm, WIN_FLATTOP); }
+int blackman_c(float *Y, const size_t L, const int exact, const size_t norm) { return window_host_cplx<float>("blackman_c", Y, L, norm, WIN_BLACKMAN, 0.f, exact != 0); }
+int blackman_z(double *Y, const size_t L, const int exact, const size_t norm) { return window_host_cplx<double>("blackman_z", Y, L, norm, WIN_BLACKMAN, 0.0, exact != 0); }
+int gauss_c(float *Y, const size_t L, const float r, const size_t norm) { return window_host_cplx<float>("gauss_c", Y, L, norm, WIN_GAUSS, r); }
+int gauss_z(double *Y, const size_t L, const double r, const size_t norm) { return window_host_cplx<double>("gauss_z", Y, L, norm, WIN_GAUSS, r); }
+int tukey_c(float *Y, const size_t L, const float r, const size_t norm) { return window_host_cplx<float>("tukey_c", Y, L, norm, WIN_TUKEY, r); }
+int tukey_z(double *Y, const size_t L, const double r, const size_t norm) { return window_host_cplx<double>("tukey_z", Y, L, norm, WIN_TUKEY, r); }
+int planck_c(float *Y, const size_t L, const float epsilon, const size_t norm) { return window_host_cplx<float>("planck_c", Y, L, norm, WIN_PLANCK, epsilon); }
+int planck_z(double *Y, const size_t L, const double epsilon, const size_t norm) { return window_host_cplx<double>("planck_z", Y, L, norm, WIN_PLANCK, epsilon); }
 int dsp_window_dev_s(float *Y_dev, const int window, const size_t L, const size_t norm, void *stream) { return window_dev<float>("dsp_window_dev_s", Y_dev, window, L, norm, stream, window == WIN_GAUSS ? 2.5f : window == WIN_TUKEY ? 0.5f : window == WIN_PLANCK ? 0.1f : 0.f); }
 int dsp_window_dev_d(double *Y_dev, const int window, const size_t L, const size_t norm, void *stream) { return window_dev<double>("dsp_window_dev_d", Y_dev, window, L, norm, stream, window == WIN_GAUSS ? 2.5 : window == WIN_TUKEY ? 0.5 : window == WIN_PLANCK ? 0.1 : 0.0); }
 int dsp_window_par_dev_s(float *Y_dev, const int window, const size_t L, const float par, const int flag, const size_t norm, void *stream) { return window_dev<float>("dsp_window_par_dev_s", Y_dev, window, L, norm, stream, par, flag != 0); }

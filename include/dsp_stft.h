@@ -100,8 +100,8 @@ int fft_fftw_z (double *Y, const double *X, const size_t R, const size_t C, cons
 
 /* reference c/hann.c:15-16, c/hamming.c:15-16, c/povey.c:15-16, c/blackmanharris.c:16-17.  The
  * window X2 of stft: symmetric, period L-1, L values; norm 0 none, 1 unit sum, 2 unit energy,
- * 3 divided by element L/2.  (The reference's _c/_z forms, which interleave a zero imaginary
- * part, are not provided: stft takes real windows only.) */
+ * 3 divided by element L/2.  The _c/_z forms (reference c/hann.c:17-18 and the like) write the same L values as
+ * interleaved complex numbers with a zero imaginary part (2 L elements). */
 int hann_s (float *Y, const size_t L, const size_t norm);
 int hann_d (double *Y, const size_t L, const size_t norm);
 int hamming_s (float *Y, const size_t L, const size_t norm);
@@ -133,6 +133,33 @@ int tukey_s (float *Y, const size_t L, const float r, const size_t norm);
 int tukey_d (double *Y, const size_t L, const double r, const size_t norm);
 int planck_s (float *Y, const size_t L, const float epsilon, const size_t norm);
 int planck_d (double *Y, const size_t L, const double epsilon, const size_t norm);
+/* the complex forms of the twelve generators (reference c/<window>.c, the _c and _z functions).  gauss_c/_z return the
+ * symmetric window; the reference mirrors their second half with the real form's offset (c/gauss.c:78,107) and
+ * copies the wrong elements there. */
+int hann_c (float *Y, const size_t L, const size_t norm);
+int hann_z (double *Y, const size_t L, const size_t norm);
+int hamming_c (float *Y, const size_t L, const size_t norm);
+int hamming_z (double *Y, const size_t L, const size_t norm);
+int povey_c (float *Y, const size_t L, const size_t norm);
+int povey_z (double *Y, const size_t L, const size_t norm);
+int blackmanharris_c (float *Y, const size_t L, const size_t norm);
+int blackmanharris_z (double *Y, const size_t L, const size_t norm);
+int bartlett_c (float *Y, const size_t L, const size_t norm);
+int bartlett_z (double *Y, const size_t L, const size_t norm);
+int triangular_c (float *Y, const size_t L, const size_t norm);
+int triangular_z (double *Y, const size_t L, const size_t norm);
+int rectangular_c (float *Y, const size_t L, const size_t norm);
+int rectangular_z (double *Y, const size_t L, const size_t norm);
+int flattop_c (float *Y, const size_t L, const size_t norm);
+int flattop_z (double *Y, const size_t L, const size_t norm);
+int blackman_c (float *Y, const size_t L, const int exact, const size_t norm);
+int blackman_z (double *Y, const size_t L, const int exact, const size_t norm);
+int gauss_c (float *Y, const size_t L, const float r, const size_t norm);
+int gauss_z (double *Y, const size_t L, const double r, const size_t norm);
+int tukey_c (float *Y, const size_t L, const float r, const size_t norm);
+int tukey_z (double *Y, const size_t L, const double r, const size_t norm);
+int planck_c (float *Y, const size_t L, const float epsilon, const size_t norm);
+int planck_z (double *Y, const size_t L, const double epsilon, const size_t norm);
 
 /* reference c/pow_compress.c:17-20.  Y[n] = f(X[n] + preg) over N values: p == 1 identity, p == 0
  * natural log, p == 0.5 sqrt, |p - 1/3| <= FLT_EPSILON cbrt, otherwise pow(., p); p in [0,1],

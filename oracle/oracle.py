@@ -336,6 +336,26 @@ def get_stft_freqs(nfft, F, fs, dtype, use_ref=False):
     return rc, Y
 
 
+def ref_window_cplx(name, L, dtype, norm=0, par=None, exact=0):
+    """The complex forms of the reference's window generators (the _c/_z functions of c/hann.c ... c/planck.c): 2 L
+    interleaved values, returned as a complex array; guard elements on each side must come back untouched."""
+    rdt = np.float32 if np.dtype(dtype) == np.complex64 else np.float64
+    s = "c" if rdt == np.float32 else "z"
+    buf = np.full(2 * L + 4, 77.0, dtype=rdt)
+    Y = buf[2:2 * L + 2]
+    f = getattr(ref(), f"{name}_{s}")
+    f.restype = _int
+    if name in ("gauss", "tukey", "planck"):
+        rc = f(_ptr(Y), _sz(L), (C.c_float if s == "c" else C.c_double)(par), _sz(norm))
+    elif name == "blackman":
+        rc = f(_ptr(Y), _sz(L), _int(exact), _sz(norm))
+    else:
+        rc = f(_ptr(Y), _sz(L), _sz(norm))
+    assert rc == 0
+    assert np.all(buf[:2] == 77.0) and np.all(buf[-2:] == 77.0), f"{name} L={L}: the reference wrote outside its 2 L values"
+    return Y.copy().view(np.complex64 if rdt == np.float32 else np.complex128)
+
+
 def ref_window(name, L, dtype, norm=0, par=None, exact=0):
     """reference window generators c/hann.c, c/hamming.c, c/povey.c, c/blackmanharris.c, c/blackman.c
     (exact), c/bartlett.c, c/triangular.c, c/rectangular.c, c/flattop.c, c/gauss.c, c/tukey.c, c/planck.c

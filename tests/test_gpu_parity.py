@@ -1120,3 +1120,21 @@ def test_window_univar_against_reference_fixtures(O, D, tag):
     # with snipped edges the reference's complex form mis-steps; frame w starts at w * stp here
     rc, fr = O.frame_univar(xc, h.size, 20, 1)
     assert np.array_equal(D.window_univar(xc, h, 20, True), fr * h[None, :])
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_complex_window_forms(D, dt):
+    """hann_c/_z ... planck_c/_z: the values of the real forms (bit for bit), each followed by a zero imaginary part
+    (what the reference's complex forms are: tests/test_oracle_semantics.py runs them)."""
+    cdt = np.complex64 if dt == np.float32 else np.complex128
+    for name in D.api.WINDOW_IDS:
+        for L in (1, 2, 31, 400, 4096):
+            for norm in (0, 1, 2, 3):
+                for exact in ((False, True) if name == "blackman" else (False,)):
+                    re = D.window(name, L, norm, dt, exact=exact)
+                    cx = D.window(name, L, norm, cdt, exact=exact)
+                    assert cx.dtype == cdt and cx.shape == (L,)
+                    assert np.array_equal(cx.real, re, equal_nan=True) and np.all(cx.imag == 0)
+    assert D.window("hann", 0, 0, cdt).size == 0
+    with pytest.raises(D.DspError):
+        D.window("hann", 8, 4, cdt)

@@ -149,3 +149,31 @@ def test_pow_compress_and_freqs_oracle_equals_reference(O, dt):
         rc2, b = O.get_stft_freqs(nfft, F, fs, dt, use_ref=True)
         assert rc == 0 and rc2 == 0 and np.array_equal(a, b)
     assert O.get_stft_freqs(8, 9, 1.0, dt)[0] == 1 and O.get_stft_freqs(8, 9, 1.0, dt, use_ref=True)[0] == 1
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_complex_window_forms_of_the_reference_are_the_real_ones_with_zero_imaginary_parts(O, dt):
+    """What the library's _c/_z generators return is stated from this: the reference's own hann_c ... planck_z
+    (c/hann.c:67-113 and the like, compiled as they lie) give the values of the _s/_d forms, each followed by 0 -- all
+    but gauss_c/_z, whose second half is a defect of the reference."""
+    if O.ref() is None:
+        pytest.skip("oracle/_ref not built")
+    cdt = np.complex64 if dt == np.float32 else np.complex128
+    pars = {"gauss": 2.5, "tukey": 0.5, "planck": 0.1}
+    for name in ("hann", "hamming", "povey", "blackmanharris", "blackman", "bartlett", "triangular", "rectangular", "flattop",
+                 "gauss", "tukey", "planck"):
+        for L in (16, 31, 400):
+            for norm in (0, 1, 2, 3):
+                re = O.ref_window(name, L, dt, norm, par=pars.get(name))
+                cx = O.ref_window_cplx(name, L, cdt, norm, par=pars.get(name))
+                if name == "gauss":
+                    # c/gauss.c:78,107: the second half is mirrored with the REAL form's offset (2 l + 1 + L % 2 elements
+                    # back instead of 4 l + 2 + 2 (L % 2)) and so copies the wrong elements; the first half is right.
+                    # The library returns the symmetric window there (include/dsp_stft.h).
+                    if norm == 0:
+                        assert np.all(cx.imag[: L // 2] == 0)
+                        assert np.allclose(cx.real[: L // 2], re[: L // 2], rtol=4 * np.finfo(dt).eps, atol=0), (name, L)
+                        assert not np.allclose(cx.real[L - L // 2:], re[L - L // 2:], rtol=1e-3, atol=0)
+                    continue
+                assert np.all(cx.imag == 0), (name, L, norm)
+                assert np.allclose(cx.real, re, rtol=4 * np.finfo(dt).eps, atol=0), (name, L, norm)

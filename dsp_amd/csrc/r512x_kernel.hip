@@ -55,6 +55,22 @@ constexpr int R512X_WAVES = 8;
 #ifndef R512X_NOSTORE
 #define R512X_NOSTORE 0         // diagnostic builds: 1 = the row stores are compiled out
 #endif
+#ifndef R512X_STAMPS
+#define R512X_STAMPS 0          // diagnostic builds: 1 = per-phase s_memtime sums into g_r512x_stamps
+#endif
+#if R512X_STAMPS
+__device__ unsigned long long g_r512x_stamps[2048 * 8];
+#define R512X_STAMP(i)                                                                            \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        unsigned long long t_;                                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");             \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        st_acc[i] += t_ - st_last; st_last = t_;                                                  \
+    } while (0)
+#else
+#define R512X_STAMP(i) do {} while (0)
+#endif
 #ifndef R512X_MINIMAL
 #define R512X_MINIMAL 0         // diagnostic builds: 1 = only the plain full-window instantiations
 #endif
@@ -213,6 +229,10 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
     bool first_step = true;
     load_span(xb, step_start(w));
 
+#if R512X_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory");
+#endif
     while (true) {
         ring_draw(drawn, cnt_addr);                       // the step after this one: asked for now, needed further down
         // The span of this step was asked for in the middle of the last one; memory operations complete in issue
@@ -220,6 +240,7 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
         if (first_step) { ring_wait_vm<0>(); } else { ring_wait_vm<5>(); }
         first_step = false;
         wave_sync();
+        R512X_STAMP(0);                                    // wait for the span
 
         // ---- input stage: the group's rows in all Q quarters, windowed; Q-point butterflies; twiddles ----
         C zz[16];
@@ -289,6 +310,7 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
                 }
             }
         }
+        R512X_STAMP(1);                                    // input stage
         dft16c<float, 16>(zz);
         wave_sync();                                       // all lanes have read the span
         // The slot takes the next step's span.  The reads of pass 1 must have RETURNED before the first load into
@@ -297,6 +319,7 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
         // workgroup's share the current span is fetched again: the number of loads per step stays fixed.
         advance();
         load_span(more ? nxb : xb, step_start(more ? nw : w));
+        R512X_STAMP(2);                                    // pass-1 transform, draw, span fetch issued
         {
             float2 *exf = ex + grp * R512_EXF + j;
 #pragma unroll
@@ -310,6 +333,7 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
             }
         }
         wave_sync();
+        R512X_STAMP(3);                                    // exchange writes
 
         // ---- pass 2: lane (group, k1 = j): 16-point FFT over the columns ----
         {
@@ -324,6 +348,7 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
         // of lane 0 itself); for r > 0: register 15 - k2 of lane 15 - j of group Q - r.
         // With A = Z_K + conj Z_(M-K), B = Z_K - conj Z_(M-K), T = -i W_nfft^K B:
         // |X_K|^2 = |A + T|^2 and |X_(M-K)|^2 = |A - T|^2.
+        R512X_STAMP(4);                                    // pass-2 reads and transform
         float pw[16];                                      // pw[k2] = P[K], pw[8 + k2] = P[M - K]
         float pmid = 4.0f * cx_norm<float>(zz[slot16(8)]); // K = M / 2: lane j == 0 of group 0 only
         const bool own0 = (r == 0) && (j == 0);
@@ -358,6 +383,7 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
         const int head = ring_block_head(yblk);
         const int sh = ring_stage_shift(head);             // value e of the block is staged at xs[sh + e]
         wave_sync();                                       // every lane has read its tile row: reuse the region
+        R512X_STAMP(5);                                    // split
         {
             float *pf = xs + sh + f * F;
 #pragma unroll
@@ -372,7 +398,9 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
 
         // ---- five stores: four of whole 16-byte vectors, one for the values before and after them.  Surplus
         // lanes repeat a valid store (same value to the same address).
+        R512X_STAMP(6);                                    // staging
         ring_store_rows<4, R512X_NOSTORE != 0>(yblk, xs + sh, head, nout, lane);
+        R512X_STAMP(7);                                    // stores issued
         if (!more) { break; }
         wave_sync();                                       // staging reads are done before the next step writes the tile
         sid = nsid; w = nw; xb = nxb; yb = nyb;
@@ -380,7 +408,19 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
     // no LDS-DMA load may land, and no draw return, after the wave has ended
     ring_wait_vm<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if R512X_STAMPS
+    if (lane == 0) {
+        const int gw = blockIdx.x * NWV + wv;
+        if (gw < 2048) { for (int i = 0; i < 8; ++i) { g_r512x_stamps[gw * 8 + i] = st_acc[i]; } }
+    }
+#endif
 }
+#if R512X_STAMPS
+extern "C" int dsp_debug_read_stamps_x(unsigned long long *dst, size_t n)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_r512x_stamps), n * sizeof(unsigned long long));
+}
+#endif
 
 // nfft 1024 or 2048; frames at ss0 + w * hop, or a table of frame starts that never decrease and are read where they
 // start; the frames of a step inside 2048 samples; every index of one signal's input and output inside 31 bits

@@ -82,6 +82,9 @@ __device__ __forceinline__ void ring_load_span(float *slot, float *dummy, const 
     if (inside) {
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
+#ifdef RING_FAKE_NV
+            if (q >= RING_FAKE_NV) { continue; }       // diagnostic builds: fewer loads (wrong results)
+#endif
             ring_glds16(src + min(q * 64 + lane, nvec - 1) * 4, __builtin_amdgcn_readfirstlane(ring_lds_addr(slot + q * 256)));
         }
     } else {

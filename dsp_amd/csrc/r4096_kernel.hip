@@ -53,7 +53,10 @@ __device__ unsigned g_r4096_take[R4096_SLOTS * 8];
 
 constexpr int R4096_PITCH = 33;                         // complex slots per exchange row
 constexpr int R4096_WAVE_C = 64 * R4096_PITCH;          // complex slots per wave (>= 2048)
-constexpr int R4096_WAVES = 8;                          // waves per workgroup (share the window table)
+#ifndef R4096_NWAVES
+#define R4096_NWAVES 8
+#endif
+constexpr int R4096_WAVES = R4096_NWAVES;               // waves per workgroup (share the window table)
 typedef float2 __attribute__((aligned(4))) float2_u;    // frame starts are only 4-byte aligned
 typedef unsigned u2v __attribute__((ext_vector_type(2)));
 typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access at 4-byte alignment
@@ -85,6 +88,15 @@ typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));   // 16-
 #endif
 #ifndef R4096_NT_STORE
 #define R4096_NT_STORE 0        // 1: rows are stored with the non-temporal hint
+#endif
+#ifndef R4096_WIN_AHEAD
+#define R4096_WIN_AHEAD 8       // run form: rows (of 16) of the next frame's window values that are read under the split of the current frame
+#endif
+#ifndef R4096_TA_AHEAD
+#define R4096_TA_AHEAD 1        // 1: run form reads the twiddle stage's per-lane factors right after the window step
+#endif
+#ifndef R4096_HACK
+#define R4096_HACK 0          // timing experiments only (wrong results): bit 0 = split without the constant factor, bit 1 = twiddle stage without the second factor, bit 2 = rows at a pitch of 2048 values and all stores on 16-byte boundaries
 #endif
 #ifndef R4096_STAMPS
 #define R4096_STAMPS 0          // diagnostic builds: 1 = per-phase s_memtime sums into g_r4096_stamps
@@ -307,6 +319,18 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         for (int g = 0; g < 4; ++g) { fetch_group(find_group(b, w0, g), g); }
     };
 
+    // RUN: the halved window of the coming frame, in the rotation that frame has; read under the split of the
+    // frame before it (the transform registers' worth of values; they are free there), so that the window
+    // step does not wait for the LDS
+    constexpr int NWA = RUN ? R4096_WIN_AHEAD : 0;
+    float4 wnext[NWA > 0 ? NWA : 1];
+    auto read_window = [&](auto rot_c) __attribute__((always_inline)) {
+        constexpr int NR = decltype(rot_c)::value;
+#pragma unroll
+        for (int i = 0; i < NWA; ++i) {
+            wnext[i] = *reinterpret_cast<const float4 *>(wtab + loff + 1024 * (((i >> 2) - NR) & 3) + 256 * (i & 3));
+        }
+    };
     Where cur{};
     if constexpr (!RUN) {
         cur = locate(fid);
@@ -344,7 +368,9 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
             for (int j = 0; j < 4; ++j) { wrow[j] = wtab + loff + 1024 * ((j - ROT) & 3); }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float4 hh = *reinterpret_cast<const float4 *>(wrow[i >> 2] + 256 * (i & 3));
+                float4 hh;
+                if (i < NWA) { hh = wnext[i]; }
+                else { hh = *reinterpret_cast<const float4 *>(wrow[i >> 2] + 256 * (i & 3)); }
                 if (i < NE) { ze[i] = C2{pre[i].x, pre[i].y}; zo[i] = C2{pre[i].z, pre[i].w}; }
                 if (!FULL) {                                 // keep data past the window out (0 * NaN)
                     ze[i].x = (256 * i < lim) ? ze[i].x : 0.f;
@@ -373,6 +399,14 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
             // follow, the old and the new samples are both live, and the frame no longer fits the registers
 #pragma unroll
             for (int i = 0; i < 16; ++i) { asm volatile("" : "+v"(ze[i]), "+v"(zo[i])); }
+        }
+        // RUN: the per-lane factors of the twiddle stage come from LDS; asked for here, two transforms ahead
+        // of their use (read where they are used, each of the 7 reads was waited for on the spot)
+        C2 taq_r[8];
+        if constexpr (RUN && R4096_TA_AHEAD) {
+#pragma unroll
+            for (int q = 1; q < 8; ++q) { taq_r[q] = twl[256 + 64 * q + lane]; }
+            __builtin_amdgcn_sched_barrier(0);
         }
         R4096_STAMP(6);
         R4096_PRIO(4, 0);
@@ -419,8 +453,8 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int bb = 1; bb < 4; ++bb) { *zp[bb] = cx_mul_second<float>(*zp[bb], tb[bb], t[bb]); }
-            if (q) {
-                const C2 taq = RUN ? twl[256 + 64 * q + lane] : ta[q];
+            if (q && !(R4096_HACK & 2)) {
+                const C2 taq = RUN ? (R4096_TA_AHEAD ? taq_r[q] : twl[256 + 64 * q + lane]) : ta[q];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int bb = 0; bb < 4; ++bb) { t[bb] = cx_mul_first<float>(*zp[bb], taq); }
@@ -496,10 +530,14 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
 
         // the registers are free from here on: start the next frame's loads under the split
         if (!RUN && nxt.inside) { load_inside(nxt, NE, 16); }
+        if constexpr (NWA > 0) {
+            read_window(rot<(ROT + 1) & 3>{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
         R4096_STAMP(4);
 
         // ---------------- split + power + store: lane handles bins k = 4 lane + c + 256 m and 2048 - k ----------------
-        float *y = Y + (RUN ? (long long)run_b * a.W + run_w0 + tpos : cur.row) * F;
+        float *y = Y + (RUN ? (long long)run_b * a.W + run_w0 + tpos : cur.row) * ((R4096_HACK & 4) ? 2048 : F);
         const C2 *zk = ex + zpos(4 * lane);                                // Z[k] at zk[256 m + c]
         const C2 *zq0 = ex + zpos(M - 4 * lane) - 768;                     // Z[2048 - 4 lane - 256 m] at zq0[256 (3 - m)]
         const C2 *zq4 = ex + zpos(M - 4 - 4 * lane) - 768;                 // Z[2048 - 4 lane - 256 m - 4 + i] at zq4[256 (3 - m) + i]
@@ -517,7 +555,9 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
                 const C2 A = cx_add_conj<float>(z, zm);
                 C2 B = cx_sub_conj<float>(z, zm);
                 // -i W4096^k B with W4096^k = W4096^(4 lane + c) W16^m
+#if !(R4096_HACK & 1)
                 if (m > 0) { B = cx_mul<float>(B, W64C[8 * m], W64C[8 * m + 1]); }
+#endif
                 const C2 Tw = cx_mul<float>(B, ow4[c]);
                 p[c] = cx_norm<float>(A + Tw); q[c] = cx_norm<float>(A - Tw);
             }
@@ -530,10 +570,10 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
             {
 #if R4096_NT_STORE
                 __builtin_nontemporal_store(float4_u{p[0], p[1], p[2], p[3]}, reinterpret_cast<float4_u *>(y + k0));
-                __builtin_nontemporal_store(float4_u{q[3], q[2], q[1], q[0]}, reinterpret_cast<float4_u *>(y + M - 3 - k0));
+                __builtin_nontemporal_store(float4_u{q[3], q[2], q[1], q[0]}, reinterpret_cast<float4_u *>(y + M - ((R4096_HACK & 4) ? 4 : 3) - k0));
 #else
                 *reinterpret_cast<float4_u *>(y + k0) = float4_u{p[0], p[1], p[2], p[3]};
-                *reinterpret_cast<float4_u *>(y + M - 3 - k0) = float4_u{q[3], q[2], q[1], q[0]};
+                *reinterpret_cast<float4_u *>(y + M - ((R4096_HACK & 4) ? 4 : 3) - k0) = float4_u{q[3], q[2], q[1], q[0]};
 #endif
             }
         }
@@ -577,6 +617,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
             asm volatile("" : "+v"(took) : "v"(pre[3].w), "v"(pre[7].w), "v"(pre[11].w), "v"(pre[15].w));
             const int nrun = f_lo + fstride + (int)__builtin_amdgcn_readfirstlane(took);
             tpos = 0;
+            if constexpr (NWA > 0) { read_window(rot<0>{}); }
             while (frame(rot<0>{}) && frame(rot<1>{}) && frame(rot<2>{}) && frame(rot<3>{})) { }
             fid = nrun;
         }
@@ -603,6 +644,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
             asm volatile("" : "+v"(took) : "v"(pre[3].w), "v"(pre[7].w), "v"(pre[11].w), "v"(pre[15].w));
             const int nrun = f_lo + fstride + (int)__builtin_amdgcn_readfirstlane(took);
             tpos = 0;
+            if constexpr (NWA > 0) { read_window(rot<0>{}); }
             while (frame(rot<0>{}) && frame(rot<1>{}) && frame(rot<2>{}) && frame(rot<3>{})) { }
             fid = nrun;
         }

@@ -7,18 +7,25 @@ win = torch.from_numpy(dsp_amd.blackmanharris(4096)).cuda()
 y = dsp_amd.stft_dev(x, win, 1024, nfft=4096)
 for _ in range(60): dsp_amd.stft_dev(x, win, 1024, nfft=4096, out=y)
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(40): dsp_amd.stft_dev(x, win, 1024, nfft=4096, out=y)
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 40
 buf = np.zeros(2048 * 8, dtype=np.uint64)
 h = C.CDLL(os.environ['DSP_AMD_LIB'])
 rc = h.dsp_debug_read_stamps4096(buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.size))
 a = buf.reshape(2048, 8).astype(np.float64)
-tot = a.sum(1)
-frames = y.shape[0] * y.shape[1] / 2048
+frames = y.shape[0] * y.shape[1] / max(1, int((a.sum(1) > 0).sum()))
 names = ['dft16x2+combine', 'tw+swap+write+sync+locate+early', 'p2 read+dft32', 'sync+zwrite+sync', 'late loads issue', 'split+stores', 'window (wait for loads)', 'shift+issue loads']
-print('rc', rc, 'mean total cycles per wave', tot.mean(), 'frames/wave', frames)
+nw = int((a.sum(1) > 0).sum())
+a = a[:nw]
+tot = a.sum(1)
+print('rc', rc, 'waves', nw, 'ms per launch %.4f' % ms, 'implied shader clock %.3f GHz' % (tot.mean() / (ms * 1e6)), 'mean total cycles per wave', tot.mean(), 'frames/wave', frames)
 for i, n in enumerate(names):
     print(f'{n:32s} {a[:, i].mean() / frames:9.0f} cyc/frame  {100 * a[:, i].mean() / tot.mean():5.1f}%')
 print('total per wave: min %.0f  p50 %.0f  p90 %.0f  max %.0f' % (tot.min(), np.percentile(tot, 50), np.percentile(tot, 90), tot.max()))
-w = tot.reshape(256, 8)
+w = tot.reshape(256, -1)
 print('per xcd mean/max:', [(int(w[x::8].mean()), int(w[x::8].max())) for x in range(8)])
 print('mean by wave slot:', [int(v) for v in w.mean(0)])
 print('std across WGs of WG-mean: %.0f ; mean within-WG std: %.0f' % (w.mean(1).std(), w.std(1).mean()))

@@ -1138,3 +1138,77 @@ def test_complex_window_forms(D, dt):
     assert D.window("hann", 0, 0, cdt).size == 0
     with pytest.raises(D.DspError):
         D.window("hann", 8, 4, cdt)
+
+
+def test_host_entry_points_from_several_threads(O, D):
+    """The C entry points are re-entrant (the reference is not: FFTW's planner, c/stft.c:53): six host threads call
+    them at once for a while -- single host-pointer transforms of both precisions, a streamed host batch (pinned
+    stages, copy threads), stft_flt with more distinct frame-start tables than the per-device cache holds (entries
+    are evicted while other threads launch with theirs), the nfft-4096 run form (its counter sets) and a thread
+    with the documented stft_flt framing selected (a per-thread setting that must not leak into the others).
+    Every result equals what the same call gave alone (the run form: to the tolerance, it deals its work at run time)."""
+    import threading
+    import torch
+    rng = np.random.default_rng(77)
+    x32 = (rng.standard_normal(48000) * 0.1).astype(np.float32)
+    x64 = (rng.standard_normal(30000) * 0.1).astype(np.float64)
+    xb = (rng.standard_normal((110, 160000)) * 0.1).astype(np.float32)            # 70 MB: streamed
+    xl = torch.randn((8, 1 << 24), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)) * 0.1   # 4096 runs of 32 frames
+    w32, w64, wp = D.hann(400, np.float32), D.hann(400, np.float64), D.povey(400, np.float32)
+    wl = torch.from_numpy(D.blackmanharris(4096)).cuda()
+    hops = [150.25 + 0.5 * i for i in range(12)]                                   # 12 tables: more than the cache keeps
+    Wf = int((48000 - 1 - 200) // hops[-1])
+
+    def flt_all():
+        return [D.stft_flt(x32, wp, Wf, 200.0, h) for h in hops]
+
+    def flt_intended():
+        D.set_flt_mode(True)
+        try:
+            return D.stft_flt(x32, wp, Wf, -45.0, 100.0)
+        finally:
+            D.set_flt_mode(False)
+
+    def long_window():
+        y = D.stft_dev(xl, wl, 1024, nfft=4096)
+        torch.cuda.synchronize()
+        return y
+
+    jobs = {
+        "stft_s": lambda: D.stft(x32, w32, 160, mn0=True),
+        "stft_d": lambda: D.stft(x64, w64, 160, lg=True),
+        "batch": lambda: D.stft_batch(xb, w32, 160),
+        "flt_tables": flt_all,
+        "flt_intended": flt_intended,
+        "flt_compat": lambda: D.stft_flt(x32, wp, Wf, -45.0, 100.0),
+        "r4096": long_window,
+    }
+    alone = {k: f() for k, f in jobs.items()}
+    assert not np.array_equal(alone["flt_intended"], alone["flt_compat"])          # the two framings differ here
+    errors = []
+
+    def worker(name, reps):
+        try:
+            for _ in range(reps):
+                got = jobs[name]()
+                want = alone[name]
+                if name == "r4096":
+                    assert float((got - want).abs().max() / want.max()) <= 1e-6
+                elif isinstance(want, list):
+                    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+                else:
+                    assert np.array_equal(got, want), name
+        except Exception as e:                                                     # noqa: BLE001 - reported below
+            errors.append((name, repr(e)))
+
+    reps = {"stft_s": 40, "stft_d": 40, "batch": 3, "flt_tables": 4, "flt_intended": 30, "flt_compat": 30, "r4096": 6}
+    threads = [threading.Thread(target=worker, args=(k, reps[k])) for k in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    rc, Yref = O.stft(x32, w32, 160, 512, 0, 1)
+    check_spec(O, alone["stft_s"], Yref)
+    rc, Yref = O.stft(xl[3, :40000].cpu().numpy(), wl.cpu().numpy(), 1024, 4096, exact=False)
+    check_spec(O, alone["r4096"][3, :Yref.shape[0] - 3].cpu().numpy(), Yref[:-3])

@@ -49,6 +49,9 @@ constexpr int R512X_WAVES = 8;
 #ifndef R512X_TWD_LDS
 #define R512X_TWD_LDS (Q == 4 || SPAN == 2048)   // where the pass-1 twiddles of the 256-point transform come from an LDS table instead of 30 registers (these instantiations spill otherwise; measured: 1024 / hop 512 0.480 -> 0.449 ms, and 6 % slower where nothing spills)
 #endif
+#ifndef R512X_TWD_AHEAD
+#define R512X_TWD_AHEAD 1       // 1: the LDS twiddles of a step are read in one go before the pass-1 transform
+#endif
 #ifndef R512X_NOLOAD
 #define R512X_NOLOAD 0          // diagnostic builds: 1 = the span loads fetch the twiddle table instead (no HBM reads)
 #endif
@@ -311,6 +314,15 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
             }
         }
         R512X_STAMP(1);                                    // input stage
+        // pass-1 twiddles from the LDS table: asked for here, ahead of the transform that precedes their use.  (Read
+        // inside the loop of the exchange writes, each read follows the write before it -- the compiler cannot tell
+        // the table from the tile -- and is waited for on the spot: 15 LDS round trips in a row.)
+        C twl[16];
+        if constexpr (R512X_TWD_LDS && R512X_TWD_AHEAD) {
+#pragma unroll
+            for (int k1 = 1; k1 < 16; ++k1) { const float2 t = ttab[k1 * 16 + j]; twl[k1] = C{t.x, t.y}; }
+            __builtin_amdgcn_sched_barrier(0);             // (the scheduler would sink the reads below the transform)
+        }
         dft16c<float, 16>(zz);
         wave_sync();                                       // all lanes have read the span
         // The slot takes the next step's span.  The reads of pass 1 must have RETURNED before the first load into
@@ -326,7 +338,8 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
             for (int k1 = 0; k1 < 16; ++k1) {
                 C v = zz[slot16(k1)];
                 if (k1 > 0) {
-                    if constexpr (R512X_TWD_LDS) { const float2 t = ttab[k1 * 16 + j]; v = cx_mul<float>(v, t.x, t.y); }
+                    if constexpr (R512X_TWD_LDS && R512X_TWD_AHEAD) { v = cx_mul<float>(v, twl[k1]); }
+                    else if constexpr (R512X_TWD_LDS) { const float2 t = ttab[k1 * 16 + j]; v = cx_mul<float>(v, t.x, t.y); }
                     else { v = cx_mul<float>(v, twd[k1]); }
                 }
                 exf[k1 * 17] = make_float2(v.x, v.y);

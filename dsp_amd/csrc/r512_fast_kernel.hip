@@ -105,6 +105,12 @@ __device__ unsigned long long g_r512f_stamps[8192 * 8];
 #ifndef R512F_TW_LDS_F64
 #define R512F_TW_LDS_F64 1      // 1: the double kernel reads its pass-1 twiddles from LDS (they do not fit in registers)
 #endif
+#ifndef R512F_TWD_AHEAD_F32
+#define R512F_TWD_AHEAD_F32 4   // twiddles read from LDS ahead of their use (0: where they are used), float instantiations with an LDS table
+#endif
+#ifndef R512F_TWD_AHEAD_F64
+#define R512F_TWD_AHEAD_F64 2   // the same for double (registers are short there)
+#endif
 #ifndef R512F_NOLOAD
 #define R512F_NOLOAD 0          // diagnostic builds: 1 = the span loads are compiled out
 #endif
@@ -424,11 +430,25 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
         }
         {
             T2 *exf = ex + f * R512_EXF + j;
+            // Twiddles from the LDS table are read TWD twiddles ahead of their use.  (Read where it is used, each
+            // follows the exchange write before it -- the compiler cannot tell the table from the tile -- and is
+            // waited for on the spot: 15 LDS round trips in a row.)
+            constexpr int TWD = TWREG ? 0 : (sizeof(T) == 4 ? R512F_TWD_AHEAD_F32 : R512F_TWD_AHEAD_F64);
+            T2 tq[16];
+            if constexpr (TWD > 0) {
+#pragma unroll
+                for (int k1 = 1; k1 <= (TWD < 15 ? TWD : 15); ++k1) { tq[k1] = ttab[k1 * 16 + j]; }
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int k1 = 0; k1 < 16; ++k1) {
                 C v = zz[slot16(k1)];
+                if constexpr (TWD > 0) {
+                    if (k1 >= 1 && k1 + TWD < 16) { tq[k1 + TWD] = ttab[(k1 + TWD) * 16 + j]; __builtin_amdgcn_sched_barrier(0); }
+                }
                 if (k1 > 0) {
                     if (TWREG) { v = cx_mul<T>(v, twd[k1]); }
+                    else if constexpr (TWD > 0) { v = cx_mul<T>(v, tq[k1].x, tq[k1].y); }
                     else { const T2 t = ttab[k1 * 16 + j]; v = cx_mul<T>(v, t.x, t.y); }
                 }
                 T2 o; o.x = v.x; o.y = v.y;

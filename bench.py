@@ -45,6 +45,10 @@ WORKLOADS = {
     "utt1x10s_f32_hann400_hop160_nfft512": ("float32", 1, 160000, "hann", 400, 160, 512, "stft"),
     "flt_f64_8ch_x_1h16k_povey400_hop160_nfft512": ("float64", 8, 57600000, "povey", 400, 160, 512, "flt"),
     "longwin_f32_8ch_x_1h48k_bh4096_hop1024_nfft4096": ("float32", 8, 172800000, "blackmanharris", 4096, 1024, 4096, "stft"),
+    # configurations 3 and 4 of BASELINE.json as single launches: all 64 float64 channels (29.5 GB in, 47.4 GB out) and
+    # 32 of the 128 float32 channels (22.1 GB in, 44.3 GB out; all 128 are 265 GB and do not fit one GPU beside anything else)
+    "flt_f64_64ch_x_1h16k_povey400_hop160_nfft512": ("float64", 64, 57600000, "povey", 400, 160, 512, "flt"),
+    "longwin_f32_32ch_x_1h48k_bh4096_hop1024_nfft4096": ("float32", 32, 172800000, "blackmanharris", 4096, 1024, 4096, "stft"),
     # the other transform lengths with kernels of their own (not configurations of BASELINE.json)
     "tel1024x10s8k_f32_hann200_hop80_nfft256": ("float32", 1024, 80000, "hann", 200, 80, 256, "stft"),
     "music64x60s44k_f32_hann1024_hop256_nfft1024": ("float32", 64, 2646000, "hann", 1024, 256, 1024, "stft"),
@@ -285,7 +289,10 @@ def main():
     x = torch.empty((B, N), dtype=tdt, device=dev)
     for b0 in range(0, B, 64):
         g.manual_seed(0xD5F0 + (rank * B + b0) // 64)
-        x[b0:b0 + 64] = torch.randn((min(64, B - b0), N), generator=g, device=dev, dtype=tdt) * 0.1
+        for b1 in range(b0, min(B, b0 + 64), 8):          # (8 at a time: the generator's stream is the same, the temporaries stay small)
+            n8 = min(8, B - b1, b0 + 64 - b1)
+            x[b1:b1 + n8] = torch.randn((n8, N), generator=g, device=dev, dtype=tdt)
+            x[b1:b1 + n8] *= 0.1
     if kind == "flt":
         W = (N - 1 - L // 2) // stp
         dsp_amd.set_flt_mode(False)

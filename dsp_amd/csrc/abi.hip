@@ -398,35 +398,71 @@ private:
 };
 
 
-// Streamed form for batches: signals go through in chunks, chunk c being staged and copied in while chunk
-// c - 1 is transformed and chunk c - 2 is copied out and unstaged (pinned stages, three streams).  The kernel
-// sees each chunk as a dense batch of its own, so the result is the batched device path's, bit for bit.
+// Streamed form of the host-pointer entry points: the work goes through in chunks, chunk c being staged and copied in
+// while chunk c - 1 is transformed and chunk c - 2 is copied out and unstaged (pinned stages, three streams).
+// A chunk is a group of whole signals (batches of short signals; the kernel sees a dense batch of its own) or, when
+// one signal alone is larger than a chunk (the reference's own calls on hour-long signals), a range of the frames
+// of one signal together with the samples those frames read -- reflected samples at the ends of the signal
+// included.  The kernel is then given the chunk as "the signal from sample lo on" (pointer moved back by lo, true
+// length N, start of the first frame moved on by w0 hops), so every frame sees the samples, and takes the branches,
+// it would in one launch over the whole signal.
 constexpr size_t STREAM_MIN_BYTES = (size_t)64 << 20;      // below this the plain three copies are faster
 constexpr size_t STREAM_CHUNK_BYTES = (size_t)48 << 20;    // input + output bytes of a chunk
+struct StreamChunk { size_t b0, nb, w0, nw, lo, n_in; };   // signals [b0, b0 + nb), frames [w0, w0 + nw), samples [lo, lo + n_in) of each
 template <typename T>
 int run_fused_host_streamed(const char *fn, int dev, T *Y, const T *X, const T *win, const FrameDesc &d)
 {
     DevState &st = g_dev[dev];
     const size_t F = (size_t)d.nfft / 2 + 1, N = (size_t)d.N, W = (size_t)d.W, B = (size_t)d.B;
     const size_t in_sig = N * sizeof(T), out_sig = W * F * sizeof(T);
-    size_t cb = STREAM_CHUNK_BYTES / (in_sig + out_sig);
-    cb = std::max<size_t>(1, std::min(cb, (B + 1) / 2));
-    const size_t nchunks = (B + cb - 1) / cb;
+    std::vector<StreamChunk> chunks;
+    size_t max_in = 0, max_out = 0;                        // elements of the largest chunk
+    if (in_sig + out_sig <= STREAM_CHUNK_BYTES && B >= 2) {
+        size_t cb = STREAM_CHUNK_BYTES / (in_sig + out_sig);
+        cb = std::max<size_t>(1, std::min(cb, (B + 1) / 2));
+        for (size_t b0 = 0; b0 < B; b0 += cb) { chunks.push_back({b0, std::min(cb, B - b0), 0, W, 0, N}); }
+        max_in = cb * N; max_out = cb * W * F;
+    } else {
+        // by frames (equally spaced frames only: the caller sees to that).  Beyond the last frame's window the
+        // kernels may read on to the end of a vector, a row or a transform length: that much is staged as well.
+        const long long stp = d.stp, L = d.L, shift = d.edge ? d.rd_shift : 0, slack = 2ll * d.nfft + 64;
+        size_t fw = STREAM_CHUNK_BYTES / (((size_t)stp + F) * sizeof(T));
+        fw = std::max<size_t>(128, fw & ~(size_t)127);
+        if (fw * 2 > W) { fw = std::max<size_t>(128, ((W + 1) / 2 + 127) & ~(size_t)127); }   // at least two chunks: something to overlap
+        for (size_t b = 0; b < B; ++b) {
+            for (size_t w0 = 0; w0 < W; w0 += fw) {
+                const size_t nw = std::min(fw, W - w0);
+                const long long first = d.ss0 + (long long)w0 * stp, last_end = d.ss0 + (long long)(w0 + nw - 1) * stp + L;
+                long long lo = first - shift, hi = last_end - shift + slack;
+                if (d.edge == 0) {
+                    if (first < 0) { hi = std::max(hi, -first); }                                  // sample -n-1 for n < 0
+                    if (last_end > (long long)N) { lo = std::min(lo, 2 * (long long)N - last_end); } // sample 2N-1-n for n >= N
+                }
+                lo = std::max(0ll, std::min(lo, (long long)N)) & ~3ll;     // (a multiple of 16 bytes: loads keep the alignment they have in one launch)
+                hi = std::max(lo, std::min(hi, (long long)N));
+                chunks.push_back({b, 1, w0, nw, (size_t)lo, (size_t)(hi - lo)});
+                max_in = std::max(max_in, (size_t)(hi - lo)); max_out = std::max(max_out, nw * F);
+            }
+        }
+    }
+    max_in += 16;
+    const size_t nchunks = chunks.size();
     constexpr int S = DevState::SLOTS;
-    if (st.cap_in < cb * in_sig || st.cap_out < cb * out_sig) {
+    if (st.cap_in < max_in * sizeof(T) || st.cap_out < max_out * sizeof(T)) {
         HIPCHK(fn, hipDeviceSynchronize());
         for (int i = 0; i < S; ++i) {
             if (st.pin_in[i]) { (void)hipHostFree(st.pin_in[i]); (void)hipHostFree(st.pin_out[i]); (void)hipFree(st.dev_in[i]); (void)hipFree(st.dev_out[i]); }
             st.pin_in[i] = st.pin_out[i] = st.dev_in[i] = st.dev_out[i] = nullptr;
         }
         st.cap_in = st.cap_out = 0;
+        const size_t ci = std::max(st.cap_in, max_in * sizeof(T)), co = std::max(st.cap_out, max_out * sizeof(T));
         for (int i = 0; i < S; ++i) {
-            HIPCHK(fn, hipHostMalloc(&st.pin_in[i], cb * in_sig, hipHostMallocDefault));
-            HIPCHK(fn, hipHostMalloc(&st.pin_out[i], cb * out_sig, hipHostMallocDefault));
-            HIPCHK(fn, hipMalloc(&st.dev_in[i], cb * in_sig));
-            HIPCHK(fn, hipMalloc(&st.dev_out[i], cb * out_sig));
+            HIPCHK(fn, hipHostMalloc(&st.pin_in[i], ci, hipHostMallocDefault));
+            HIPCHK(fn, hipHostMalloc(&st.pin_out[i], co, hipHostMallocDefault));
+            HIPCHK(fn, hipMalloc(&st.dev_in[i], ci));
+            HIPCHK(fn, hipMalloc(&st.dev_out[i], co));
         }
-        st.cap_in = cb * in_sig; st.cap_out = cb * out_sig;
+        st.cap_in = ci; st.cap_out = co;
     }
     if (!st.st_in) {
         HIPCHK(fn, hipStreamCreateWithFlags(&st.st_in, hipStreamNonBlocking));
@@ -447,26 +483,28 @@ int run_fused_host_streamed(const char *fn, int dev, T *Y, const T *X, const T *
     for (size_t c = 0; c < nchunks + LAG; ++c) {
         if (c < nchunks && !rc) {
             const int sl = (int)(c % S);
-            const size_t b0 = c * cb, nb = std::min(cb, B - b0);
+            const StreamChunk &k = chunks[c];
             // (the slot's stages and device buffers are free: chunk c - S was unstaged in the iteration before)
-            pool.copy_rows(st.pin_in[sl], in_sig, X + b0 * (size_t)d.ldx, (size_t)d.ldx * sizeof(T), in_sig, nb);
-            HIPCHK(fn, hipMemcpyAsync(st.dev_in[sl], st.pin_in[sl], nb * in_sig, hipMemcpyHostToDevice, st.st_in));
+            const size_t row = k.n_in * sizeof(T);
+            pool.copy_rows(st.pin_in[sl], row, X + k.b0 * (size_t)d.ldx + k.lo, (size_t)d.ldx * sizeof(T), row, k.nb);
+            HIPCHK(fn, hipMemcpyAsync(st.dev_in[sl], st.pin_in[sl], k.nb * row, hipMemcpyHostToDevice, st.st_in));
             HIPCHK(fn, hipEventRecord(st.ev_in[sl], st.st_in));
             HIPCHK(fn, hipStreamWaitEvent(st.st_k, st.ev_in[sl], 0));
             FrameDesc dc = d;
-            dc.B = (int)nb; dc.ldx = (long long)N;
-            rc = run_fused<T>(fn, dev, (T *)st.dev_out[sl], (const T *)st.dev_in[sl], (const T *)dw, dc, st.st_k, nullptr, nullptr);
+            dc.B = (int)k.nb; dc.ldx = (long long)k.n_in; dc.W = (int)k.nw;
+            dc.ss0 = d.ss0 + (long long)k.w0 * d.stp;
+            rc = run_fused<T>(fn, dev, (T *)st.dev_out[sl], (const T *)st.dev_in[sl] - k.lo, (const T *)dw, dc, st.st_k, nullptr, nullptr);
             HIPCHK(fn, hipEventRecord(st.ev_k[sl], st.st_k));
             HIPCHK(fn, hipStreamWaitEvent(st.st_out, st.ev_k[sl], 0));
-            HIPCHK(fn, hipMemcpyAsync(st.pin_out[sl], st.dev_out[sl], nb * out_sig, hipMemcpyDeviceToHost, st.st_out));
+            HIPCHK(fn, hipMemcpyAsync(st.pin_out[sl], st.dev_out[sl], k.nb * k.nw * F * sizeof(T), hipMemcpyDeviceToHost, st.st_out));
             HIPCHK(fn, hipEventRecord(st.ev_out[sl], st.st_out));
         }
         if (c >= LAG) {
-            const size_t cd = c - LAG;
-            const int sl = (int)(cd % S);
-            const size_t b0 = cd * cb, nb = std::min(cb, B - b0);
+            const StreamChunk &k = chunks[c - LAG];
+            const int sl = (int)((c - LAG) % S);
             HIPCHK(fn, hipEventSynchronize(st.ev_out[sl]));
-            if (!rc) { pool.copy_rows(Y + b0 * W * F, out_sig, st.pin_out[sl], out_sig, out_sig, nb); }
+            const size_t row = k.nw * F * sizeof(T);
+            if (!rc) { pool.copy_rows(Y + (k.b0 * W + k.w0) * F, out_sig, st.pin_out[sl], row, row, k.nb); }
         }
     }
     return rc;
@@ -481,8 +519,8 @@ int run_fused_host(const char *fn, int dev, T *Y, const T *X, const T *win, Fram
     std::lock_guard<std::mutex> lk(st.ws_mu);
     const size_t F = (size_t)d.nfft / 2 + 1;
     const size_t y_elems = (size_t)d.B * (size_t)d.W * F;
-    if (d.B >= 2 && d.tbl == nullptr && (x_elems + y_elems) * sizeof(T) >= STREAM_MIN_BYTES &&
-        ((size_t)d.N + (size_t)d.W * F) * sizeof(T) <= ((size_t)512 << 20)) {
+    if (d.tbl == nullptr && (x_elems + y_elems) * sizeof(T) >= STREAM_MIN_BYTES &&
+        (d.B >= 2 || d.W >= 256) && d.N >= d.L) {
         return run_fused_host_streamed<T>(fn, dev, Y, X, win, d);
     }
     void *dx, *dy, *dw;

@@ -1212,3 +1212,52 @@ def test_host_entry_points_from_several_threads(O, D):
     check_spec(O, alone["stft_s"], Yref)
     rc, Yref = O.stft(xl[3, :40000].cpu().numpy(), wl.cpu().numpy(), 1024, 4096, exact=False)
     check_spec(O, alone["r4096"][3, :Yref.shape[0] - 3].cpu().numpy(), Yref[:-3])
+
+
+def test_host_long_signal_streamed_by_frames(O, D):
+    """One long signal through the reference's own host-pointer entry points (stft_s/_d, stft_flt_s/_d: configurations
+    3 and 4 of the benchmark list are 64 / 128 such calls): from 64 MB of input + output on the call goes through in
+    ranges of frames, each with the samples it reads (the reflected ones at the ends of the signal included), copies
+    overlapped with the kernel.  Same bits as one launch over the whole signal on the device (nfft 4096: to the
+    tolerance, its run form transforms a frame rotated by a multiple of a quarter of its length, which depends on
+    where a range starts), and equal to the oracle at both ends and across the first boundary between two ranges."""
+    import torch
+    rng = np.random.default_rng(99)
+    for dt, N in ((np.float32, 30_000_000), (np.float64, 12_000_017)):
+        x = (rng.standard_normal(N) * 0.1).astype(dt)
+        xd = torch.from_numpy(x).cuda()
+        win = D.hann(400, dt)
+        wd = torch.from_numpy(win).cuda()
+        Yh = D.stft(x, win, 160, mn0=True)
+        Yd = D.stft_dev(xd[None, :], wd, 160, mn0=True)[0].cpu().numpy()
+        assert np.array_equal(Yh, Yd)
+        # both ends against the oracle (the last frames of the signal's tail are those of the whole signal)
+        rc, Yref = O.stft(x[:20000], win, 160, 512, 0, 1)
+        check_spec(O, Yh[:100], Yref[:100])
+        tail = 160 * 120 + (N % 160)
+        rc, Yref = O.stft(x[-tail:], win, 160, 512, 0, 1)
+        check_spec(O, Yh[-100:], Yref[-100:])
+        # stft_flt with a start of the first frame above 0 (reference framing: every read 100 samples early) and with
+        # the documented framing
+        W = (N - 1 - 300) // 160
+        for intended in (False, True):
+            D.set_flt_mode(intended)
+            try:
+                Zh = D.stft_flt(x, win, W, 300.0, 160.0)
+                Zd = D.stft_flt_dev(xd[None, :], wd, W, 300.0, 160.0)[0].cpu().numpy()
+            finally:
+                D.set_flt_mode(False)
+            assert np.array_equal(Zh, Zd)
+        del Yh, Yd, Zh, Zd
+    # other kernel families: nfft 1024 (hop 256), nfft 4096 (hop 1024: run form inside the ranges), odd hop
+    x = (rng.standard_normal(40_000_000) * 0.1).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    for (L, hop, nfft, exact) in ((1024, 256, 1024, True), (4096, 1024, 4096, False), (400, 161, 512, True), (200, 80, 256, True)):
+        win = D.blackmanharris(L, np.float32)
+        Yh = D.stft(x, win, hop, nfft=nfft)
+        Yd = D.stft_dev(xd[None, :], torch.from_numpy(win).cuda(), hop, nfft=nfft)[0].cpu().numpy()
+        if exact:
+            assert np.array_equal(Yh, Yd), (L, hop, nfft)
+        else:
+            assert O.normalised_err(Yh, Yd) <= 1e-6
+        del Yh, Yd

@@ -31,6 +31,8 @@ thread_local int tl_device = -1;             // -1: whatever device is current
 // per calling thread, like the device: two threads that want different framings do not disturb each other
 thread_local int tl_flt_intended = 0;
 thread_local int tl_force_generic = 0;
+// the host copy of the frame-start table that the calling thread's last flt_desc() came to (empty: equally spaced frames)
+thread_local std::shared_ptr<std::vector<int>> tl_flt_htbl;
 
 #define HIPCHK(fn, call)                                                                          \
     do {                                                                                          \
@@ -56,6 +58,7 @@ struct FltFraming {
     long long ss0 = 0, rd_shift = 0;
     int stp = 1, tbl_reach = -1;
     std::shared_ptr<int> tbl;                 // empty: equally spaced frames
+    std::shared_ptr<std::vector<int>> htbl;   // the table on the host (the streamed host path cuts it into ranges of frames)
 };
 constexpr size_t FLT_CACHE = 32, FLT_TABLES = 8;
 
@@ -194,6 +197,7 @@ int flt_desc(const char *fn, int dev, FrameDesc &d, size_t B, size_t N, size_t l
     auto apply = [&](const FltFraming &f) {
         d.ss0 = f.ss0; d.stp = f.stp; d.rd_shift = f.rd_shift; d.tbl_reach = f.tbl_reach;
         hold = f.tbl; d.tbl = f.tbl.get();
+        tl_flt_htbl = f.htbl;
     };
     DevState &st = g_dev[dev];
     {
@@ -235,6 +239,7 @@ int flt_desc(const char *fn, int dev, FrameDesc &d, size_t B, size_t N, size_t l
         HIPCHK(fn, hipMalloc((void **)&p, tbl.size() * sizeof(int)));
         f.tbl = std::shared_ptr<int>(p, [](int *q) { (void)hipFree(q); });
         HIPCHK(fn, hipMemcpy(p, tbl.data(), tbl.size() * sizeof(int), hipMemcpyHostToDevice));
+        f.htbl = std::make_shared<std::vector<int>>(std::move(tbl));
     }
     apply(f);
     std::list<std::pair<FltKey, FltFraming>> dropped;          // freed after the lock is released
@@ -410,7 +415,7 @@ constexpr size_t STREAM_MIN_BYTES = (size_t)64 << 20;      // below this the pla
 constexpr size_t STREAM_CHUNK_BYTES = (size_t)48 << 20;    // input + output bytes of a chunk
 struct StreamChunk { size_t b0, nb, w0, nw, lo, n_in; };   // signals [b0, b0 + nb), frames [w0, w0 + nw), samples [lo, lo + n_in) of each
 template <typename T>
-int run_fused_host_streamed(const char *fn, int dev, T *Y, const T *X, const T *win, const FrameDesc &d)
+int run_fused_host_streamed(const char *fn, int dev, T *Y, const T *X, const T *win, const FrameDesc &d, const int *htbl)
 {
     DevState &st = g_dev[dev];
     const size_t F = (size_t)d.nfft / 2 + 1, N = (size_t)d.N, W = (size_t)d.W, B = (size_t)d.B;
@@ -423,18 +428,32 @@ int run_fused_host_streamed(const char *fn, int dev, T *Y, const T *X, const T *
         for (size_t b0 = 0; b0 < B; b0 += cb) { chunks.push_back({b0, std::min(cb, B - b0), 0, W, 0, N}); }
         max_in = cb * N; max_out = cb * W * F;
     } else {
-        // by frames (equally spaced frames only: the caller sees to that).  Beyond the last frame's window the
-        // kernels may read on to the end of a vector, a row or a transform length: that much is staged as well.
-        const long long stp = d.stp, L = d.L, shift = d.edge ? d.rd_shift : 0, slack = 2ll * d.nfft + 64;
+        // by frames.  Beyond the last frame's window the kernels may read on to the end of a vector, a row or a
+        // transform length: that much is staged as well.  htbl: the frames' (start, read start) pairs when they are
+        // not equally spaced (stft_flt with a non-integral hop; zero edges).
+        const long long L = d.L, shift = d.edge ? d.rd_shift : 0, slack = 2ll * d.nfft + 4096;       // (a step's span reaches up to 1536 samples past its first frame whatever its frames)
+        const long long stp = htbl ? std::max(1ll, ((long long)htbl[2 * (W - 1)] - htbl[0]) / (long long)std::max<size_t>(1, W - 1)) : d.stp;
         size_t fw = STREAM_CHUNK_BYTES / (((size_t)stp + F) * sizeof(T));
         fw = std::max<size_t>(128, fw & ~(size_t)127);
         if (fw * 2 > W) { fw = std::max<size_t>(128, ((W + 1) / 2 + 127) & ~(size_t)127); }   // at least two chunks: something to overlap
         for (size_t b = 0; b < B; ++b) {
             for (size_t w0 = 0; w0 < W; w0 += fw) {
                 const size_t nw = std::min(fw, W - w0);
+                long long lo, hi;
+                if (htbl) {
+                    lo = (long long)N; hi = 0;
+                    for (size_t w = w0; w < w0 + nw; ++w) {
+                        // the frame reads X[n - (ss - rs)] for its n inside the signal
+                        const long long ss = htbl[2 * w], off = ss - htbl[2 * w + 1];
+                        const long long a = std::max(ss, 0ll), b = std::min(ss + L, (long long)N);
+                        if (b > a) { lo = std::min(lo, a - off); hi = std::max(hi, b - off); }
+                    }
+                    if (hi <= lo) { lo = 0; hi = 0; }
+                    hi += slack;
+                }
                 const long long first = d.ss0 + (long long)w0 * stp, last_end = d.ss0 + (long long)(w0 + nw - 1) * stp + L;
-                long long lo = first - shift, hi = last_end - shift + slack;
-                if (d.edge == 0) {
+                if (!htbl) { lo = first - shift; hi = last_end - shift + slack; }
+                if (!htbl && d.edge == 0) {
                     if (first < 0) { hi = std::max(hi, -first); }                                  // sample -n-1 for n < 0
                     if (last_end > (long long)N) { lo = std::min(lo, 2 * (long long)N - last_end); } // sample 2N-1-n for n >= N
                 }
@@ -493,6 +512,7 @@ int run_fused_host_streamed(const char *fn, int dev, T *Y, const T *X, const T *
             FrameDesc dc = d;
             dc.B = (int)k.nb; dc.ldx = (long long)k.n_in; dc.W = (int)k.nw;
             dc.ss0 = d.ss0 + (long long)k.w0 * d.stp;
+            if (d.tbl) { dc.tbl = d.tbl + 2 * k.w0; }
             rc = run_fused<T>(fn, dev, (T *)st.dev_out[sl], (const T *)st.dev_in[sl] - k.lo, (const T *)dw, dc, st.st_k, nullptr, nullptr);
             HIPCHK(fn, hipEventRecord(st.ev_k[sl], st.st_k));
             HIPCHK(fn, hipStreamWaitEvent(st.st_out, st.ev_k[sl], 0));
@@ -512,16 +532,16 @@ int run_fused_host_streamed(const char *fn, int dev, T *Y, const T *X, const T *
 
 // host-pointer form: copy in, compute on the null stream, copy out (blocking)
 template <typename T>
-int run_fused_host(const char *fn, int dev, T *Y, const T *X, const T *win, FrameDesc &d, size_t x_elems)
+int run_fused_host(const char *fn, int dev, T *Y, const T *X, const T *win, FrameDesc &d, size_t x_elems, const int *htbl = nullptr)
 {
     if (d.W == 0 || d.B == 0) { return 0; }
     DevState &st = g_dev[dev];
     std::lock_guard<std::mutex> lk(st.ws_mu);
     const size_t F = (size_t)d.nfft / 2 + 1;
     const size_t y_elems = (size_t)d.B * (size_t)d.W * F;
-    if (d.tbl == nullptr && (x_elems + y_elems) * sizeof(T) >= STREAM_MIN_BYTES &&
+    if ((d.tbl == nullptr || (htbl != nullptr && d.B == 1)) && (x_elems + y_elems) * sizeof(T) >= STREAM_MIN_BYTES &&
         (d.B >= 2 || d.W >= 256) && d.N >= d.L) {
-        return run_fused_host_streamed<T>(fn, dev, Y, X, win, d);
+        return run_fused_host_streamed<T>(fn, dev, Y, X, win, d, d.tbl ? htbl : nullptr);
     }
     void *dx, *dy, *dw;
     if (ws_reserve(fn, st, 0, x_elems * sizeof(T), dx)) { return 1; }
@@ -561,7 +581,8 @@ int stft_flt_host(const char *fn, T *Y, const T *X, const T *win, size_t N, size
     }
     if (use_device(fn, dev)) { return 1; }
     if (flt_desc<T>(fn, dev, d, 1, N, N, L, W, nfft, c0, stp, mn0, amp, lg, !tl_flt_intended, true, hold, stp_min)) { return 1; }
-    return run_fused_host<T>(fn, dev, Y, X, win, d, N);
+    const std::shared_ptr<std::vector<int>> htbl = tl_flt_htbl;      // (held for the call: the cache may drop its entry meanwhile)
+    return run_fused_host<T>(fn, dev, Y, X, win, d, N, (d.tbl && htbl) ? htbl->data() : nullptr);
 }
 
 template <typename T>

@@ -235,7 +235,7 @@ int dsp_stft_flt_batch_dev_strided_s (float *Y_dev, const float *X_dev, const fl
 int dsp_stft_flt_batch_dev_strided_d (double *Y_dev, const double *X_dev, const double *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t incx, const size_t L, const size_t W, const size_t nfft, const double c0, const double stp, const int mn0, const int amp, const int lg, void *stream);
 
 /* Batched host-pointer forms: X[b*ldx + n], Y[b][W][F]; copies in, computes, copies out.  Calls that move 64 MB
- * and more (these, and stft_s/_d and stft_flt_s/_d with an integral hop on one long signal) are streamed through pinned
+ * and more (these, and stft_s/_d and stft_flt_s/_d on one long signal) are streamed through pinned
  * stages in chunks -- groups of signals, or ranges of the frames of one signal with the samples they read -- with
  * copy in, kernel and copy out overlapped; the staging copies run on up to 12 threads, DSP_COPY_THREADS overrides. */
 int dsp_stft_batch_s (float *Y, const float *X, const float *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg);

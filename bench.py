@@ -188,6 +188,31 @@ def config1_extras(dsp_amd, x, win_h, stp, nfft):
         torch.cuda.synchronize()
     dev_us = (time.perf_counter() - t0) / 200 * 1e6
     out = {"stft_s_host_pointers_us_per_call": host_us, "stft_batch_dev_plus_sync_us_per_call": dev_us}
+    # a serving loop of single utterances is launch-bound: 100 calls of the allocation-free entry point captured into one
+    # HIP graph and replayed, against the same 100 calls enqueued one by one (both without a sync in between)
+    try:
+        import ctypes as C
+        from dsp_amd._lib import lib
+
+        def na_call():
+            return lib().dsp_stft_batch_dev_noalloc_s(C.c_void_p(y.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(win.data_ptr()), 1, x.shape[1], x.shape[1],
+                                                      win.numel(), nfft, stp, 0, 0, 0, 0, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert na_call() == 0
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for _ in range(100):
+                assert na_call() == 0
+        for fn, key in ((graph.replay, "graph_of_100_calls_us_per_call"), (lambda: [na_call() for _ in range(100)], "enqueued_100_calls_us_per_call")):
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()
+            out[key] = (time.perf_counter() - t0) / 20 / 100 * 1e6
+    except Exception as e:  # noqa: BLE001
+        out["graph_of_100_calls_us_per_call"] = f"{type(e).__name__}: {e}"
     # the kernel alone, warm (its 1.7 MB working set never leaves the caches) and cold (512 MB written between launches)
     scrub = torch.empty(128 << 20, dtype=torch.float32, device=x.device)
     for name, cold in (("kernel_us_warm", False), ("kernel_us_cold", True)):

@@ -85,3 +85,49 @@ def test_noalloc_rejects_sizes_beyond_its_limit(capfd):
     win = torch.ones(300, device="cuda")
     assert _call("dsp_stft_batch_dev_noalloc_s", y, x, win, 100, 300, False, False, False, False) == 1
     assert "power of two" in capfd.readouterr().err
+
+
+@pytest.mark.parametrize("nfft,L,stp,B,N,run_form", [(512, 400, 160, 4, 160000, False), (4096, 4096, 1024, 3, 1024 * 150, True)])
+def test_noalloc_under_graph_capture(O, nfft, L, stp, B, N, run_form):
+    """What the entry point is for: it is called while its stream is being captured into a HIP graph (a call that
+    allocated would fail the capture), and the graph is replayed on new input.  The replays equal direct calls on
+    the same input bit for bit (the 4096 run form, whose work is dealt at run time: to the tolerance); its
+    counter clear (a memset node) replays with the kernel."""
+    import torch
+    import dsp_amd
+    old = os.environ.get("DSP_R4096_MIN_RUNS")
+    if run_form:
+        os.environ["DSP_R4096_MIN_RUNS"] = "1"
+    try:
+        g = torch.Generator(device="cuda").manual_seed(11)
+        x = torch.randn((B, N), device="cuda", generator=g) * 0.1
+        win = torch.from_numpy(dsp_amd.hann(L)).cuda()
+        W, F = dsp_amd.num_frames(N, L, stp, False), nfft // 2 + 1
+        y_direct = torch.empty((B, W, F), device="cuda")
+        y_graph = torch.full((B, W, F), float("nan"), device="cuda")
+        # first call outside the capture: the tables of the static array are filled once per device
+        assert _call("dsp_stft_batch_dev_noalloc_s", y_direct, x, win, stp, nfft, False, True, False, False) == 0
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            rc = _call("dsp_stft_batch_dev_noalloc_s", y_graph, x, win, stp, nfft, False, True, False, False)
+        assert rc == 0
+        for seed in (12, 13):
+            x.copy_(torch.randn((B, N), device="cuda", generator=g.manual_seed(seed)) * 0.1)
+            graph.replay()
+            assert _call("dsp_stft_batch_dev_noalloc_s", y_direct, x, win, stp, nfft, False, True, False, False) == 0
+            torch.cuda.synchronize()
+            a, b = y_graph.cpu().numpy(), y_direct.cpu().numpy()
+            assert not np.any(np.isnan(a))
+            if run_form:
+                assert max(O.normalised_err(a[i], b[i]) for i in range(B)) <= 1e-6
+            else:
+                assert np.array_equal(a, b)
+        rc, ref = O.stft(x[1].cpu().numpy(), win.cpu().numpy(), stp, nfft, 0, 1, exact=False)
+        assert O.normalised_err(y_graph[1].cpu().numpy(), ref) <= TOL[np.dtype(np.float32)]
+    finally:
+        if run_form:
+            if old is None:
+                del os.environ["DSP_R4096_MIN_RUNS"]
+            else:
+                os.environ["DSP_R4096_MIN_RUNS"] = old

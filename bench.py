@@ -255,7 +255,7 @@ def gather_leg(x, win, B, world, rank, compute, chunks, sync, **kw):
     y, full = stft_sharded(x, win, world * B, rank, world, gather="root", compute=compute, chunks=1, **kw)
     sync()
     res["compute_then_gather_ms"] = (time.perf_counter() - t0) * 1e3
-    del full
+    del full, y
     sync()
     t0 = time.perf_counter()
     y, full = stft_sharded(x, win, world * B, rank, world, gather="root", compute=compute, chunks=chunks, **kw)

@@ -87,9 +87,11 @@ def stft_sharded(x_shard, win, B_total, rank=None, world=None, gather="none", co
         return y, full[:B_total]
     if gather == "root":
         if rank == 0:
-            parts = [torch.empty_like(send) for _ in range(world)]
+            # received straight into their place in Y[B_total, W, F] (no second copy of world * per signals)
+            full = torch.empty((world * per, W, F), dtype=y.dtype, device=y.device)
+            parts = [full[r * per:(r + 1) * per] for r in range(world)]
             dist.gather(send, parts, dst=_root_of(group), group=group)
-            return y, torch.cat(parts, dim=0)[:B_total]
+            return y, full[:B_total]
         dist.gather(send, None, dst=_root_of(group), group=group)
         return y, None
     raise ValueError(f"gather must be 'none', 'root' or 'all', not {gather!r}")

@@ -86,6 +86,9 @@ typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));   // 16-
 #ifndef R4096_RUN
 #define R4096_RUN 32            // frames per run of the run form
 #endif
+#ifndef R4096_NT_LOAD
+#define R4096_NT_LOAD 0         // 1: the run form's sample loads carry the non-temporal hint (every sample is read once)
+#endif
 #ifndef R4096_NT_STORE
 #define R4096_NT_STORE 0        // 1: rows are stored with the non-temporal hint
 #endif
@@ -302,7 +305,11 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         if (q.inside) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+#if R4096_NT_LOAD
+                const float4_u v = __builtin_nontemporal_load(reinterpret_cast<const float4_u *>(q.src + 256 * r));
+#else
                 const float4_u v = *reinterpret_cast<const float4_u *>(q.src + 256 * r);
+#endif
                 pre[4 * j + r] = make_float4(v.x, v.y, v.z, v.w);
             }
         } else {

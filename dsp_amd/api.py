@@ -95,6 +95,24 @@ def stft_batch(x, win, stp=160, snip_edges=False, mn0=False, amp=False, lg=False
     return Y
 
 
+def stft_flt_batch(x, win, W, c0=0.0, stp=160.0, mn0=False, amp=False, lg=False, nfft=None):
+    """dsp_stft_flt_batch_s / _d.  x: [B, N] (rows may be strided); returns Y[B, W, F]."""
+    x = np.asarray(x)
+    if x.ndim != 2 or x.strides[1] != x.itemsize or (x.shape[0] > 1 and x.strides[0] % x.itemsize):
+        x = np.ascontiguousarray(x)
+    s = _real_sfx(x.dtype)
+    win = np.ascontiguousarray(win, dtype=x.dtype)
+    B, N = x.shape
+    ldx = x.strides[0] // x.itemsize if B > 1 else N
+    L = win.size
+    nfft = nextpow2(L) if nfft is None else int(nfft)
+    Y = np.empty((B, W, nfft // 2 + 1), dtype=x.dtype)
+    rc = getattr(lib(), f"dsp_stft_flt_batch_{s}")(_p(Y), _p(x), _p(win), B, N, ldx, L, W, nfft, float(c0), float(stp),
+                                                   int(bool(mn0)), int(bool(amp)), int(bool(lg)))
+    _check(rc, f"dsp_stft_flt_batch_{s}")
+    return Y
+
+
 def shard_range(B, rank, world):
     """dsp_shard_range: the block [lo, hi) of B signals that GPU `rank` of `world` takes."""
     lo, hi = C.c_size_t(0), C.c_size_t(0)

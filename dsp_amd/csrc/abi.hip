@@ -539,7 +539,7 @@ int run_fused_host(const char *fn, int dev, T *Y, const T *X, const T *win, Fram
     std::lock_guard<std::mutex> lk(st.ws_mu);
     const size_t F = (size_t)d.nfft / 2 + 1;
     const size_t y_elems = (size_t)d.B * (size_t)d.W * F;
-    if ((d.tbl == nullptr || (htbl != nullptr && d.B == 1)) && (x_elems + y_elems) * sizeof(T) >= STREAM_MIN_BYTES &&
+    if ((d.tbl == nullptr || htbl != nullptr) && (x_elems + y_elems) * sizeof(T) >= STREAM_MIN_BYTES &&
         (d.B >= 2 || d.W >= 256) && d.N >= d.L) {
         return run_fused_host_streamed<T>(fn, dev, Y, X, win, d, d.tbl ? htbl : nullptr);
     }
@@ -569,20 +569,23 @@ int stft_host(const char *fn, T *Y, const T *X, const T *win, size_t B, size_t N
 
 template <typename T>
 int stft_flt_host(const char *fn, T *Y, const T *X, const T *win, size_t N, size_t L, size_t W, size_t nfft, T c0, T stp,
-                  int mn0, int amp, int lg)
+                  int mn0, int amp, int lg, size_t B = 1, size_t ldx = 0)
 {
+    if (B <= 1) { ldx = N; }
     // argument checks come before any device work, as in the reference
     FrameDesc d;
     int dev = 0;
     std::shared_ptr<int> hold;
     const T stp_min = (T)FLT_EPSILON;             // both precisions: reference c/stft_flt.c:40,139
     if (W > N || L > N || L < 1u || N < 1u || c0 > (T)(N - 1u) || stp < stp_min || nfft < L || nfft < 2u || W == 0) {
-        return flt_desc<T>(fn, 0, d, 1, N, N, L, W, nfft, c0, stp, mn0, amp, lg, !tl_flt_intended, true, hold, stp_min);
+        return flt_desc<T>(fn, 0, d, B, N, ldx, L, W, nfft, c0, stp, mn0, amp, lg, !tl_flt_intended, true, hold, stp_min);
     }
+    if (B == 0) { return 0; }
+    if (ldx < N) { fprintf(stderr, "error in %s: ldx must be >= N\n", fn); return 1; }
     if (use_device(fn, dev)) { return 1; }
-    if (flt_desc<T>(fn, dev, d, 1, N, N, L, W, nfft, c0, stp, mn0, amp, lg, !tl_flt_intended, true, hold, stp_min)) { return 1; }
+    if (flt_desc<T>(fn, dev, d, B, N, ldx, L, W, nfft, c0, stp, mn0, amp, lg, !tl_flt_intended, true, hold, stp_min)) { return 1; }
     const std::shared_ptr<std::vector<int>> htbl = tl_flt_htbl;      // (held for the call: the cache may drop its entry meanwhile)
-    return run_fused_host<T>(fn, dev, Y, X, win, d, N, (d.tbl && htbl) ? htbl->data() : nullptr);
+    return run_fused_host<T>(fn, dev, Y, X, win, d, (B - 1) * ldx + N, (d.tbl && htbl) ? htbl->data() : nullptr);
 }
 
 template <typename T>
@@ -1372,6 +1375,11 @@ int dsp_stft_flt_batch_dev_s(float *Y_dev, const float *X_dev, const float *win_
 { return stft_flt_dev<float>("dsp_stft_flt_batch_dev_s", Y_dev, X_dev, win_dev, B, N, ldx, L, W, nfft, c0, stp, mn0, amp, lg, stream); }
 int dsp_stft_flt_batch_dev_d(double *Y_dev, const double *X_dev, const double *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t W, const size_t nfft, const double c0, const double stp, const int mn0, const int amp, const int lg, void *stream)
 { return stft_flt_dev<double>("dsp_stft_flt_batch_dev_d", Y_dev, X_dev, win_dev, B, N, ldx, L, W, nfft, c0, stp, mn0, amp, lg, stream); }
+
+int dsp_stft_flt_batch_s(float *Y, const float *X, const float *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t W, const size_t nfft, const float c0, const float stp, const int mn0, const int amp, const int lg)
+{ return stft_flt_host<float>("dsp_stft_flt_batch_s", Y, X, win, N, L, W, nfft, c0, stp, mn0, amp, lg, B, ldx); }
+int dsp_stft_flt_batch_d(double *Y, const double *X, const double *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t W, const size_t nfft, const double c0, const double stp, const int mn0, const int amp, const int lg)
+{ return stft_flt_host<double>("dsp_stft_flt_batch_d", Y, X, win, N, L, W, nfft, c0, stp, mn0, amp, lg, B, ldx); }
 
 int dsp_stft_batch_s(float *Y, const float *X, const float *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg)
 {

@@ -241,6 +241,11 @@ int dsp_stft_flt_batch_dev_strided_d (double *Y_dev, const double *X_dev, const 
 int dsp_stft_batch_s (float *Y, const float *X, const float *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg);
 int dsp_stft_batch_d (double *Y, const double *X, const double *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg);
 
+/* The same for the stft_flt framing (one window, one W, c0 and stp for all B signals: the 64 channels of a multivariate
+ * recording in one call instead of 64 stft_flt_d calls); streamed like the above. */
+int dsp_stft_flt_batch_s (float *Y, const float *X, const float *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t W, const size_t nfft, const float c0, const float stp, const int mn0, const int amp, const int lg);
+int dsp_stft_flt_batch_d (double *Y, const double *X, const double *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t W, const size_t nfft, const double c0, const double stp, const int mn0, const int amp, const int lg);
+
 /* Several GPUs from one process (the reference is one process, src/stft.cpp:219).  The B signals are split in
  * contiguous blocks, GPU g of ngpu taking signals [lo, hi) = dsp_shard_range(B, g, ngpu): blocks of
  * ceil(B / ngpu), the last ones short or empty.  No data crosses between GPUs on the way: every signal is

@@ -1266,3 +1266,30 @@ def test_host_long_signal_streamed_by_frames(O, D):
         else:
             assert O.normalised_err(Yh, Yd) <= 1e-6
         del Yh, Yd
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_stft_flt_host_batch(O, D, dt):
+    """dsp_stft_flt_batch_s/_d, the host-pointer form of stft_flt for B signals (a multivariate recording in one call):
+    every signal has the bits of the reference's own stft_flt call on it; rows with a stride; a batch large enough to be
+    streamed (groups of signals for short ones, ranges of frames for long ones), with an integral hop and with a table
+    of frame starts."""
+    rng = np.random.default_rng(31)
+    win = D.povey(400, dt)
+    buf = (rng.standard_normal((5, 20000 + 16)) * 0.1).astype(dt)
+    for xs in (np.ascontiguousarray(buf[:, :20000]), buf[:, 8:20008]):
+        for (c0, stp) in ((200.0, 160.0), (-45.0, 100.0), (300.0, 160.5)):
+            W = int((20000 - 1 - max(c0, 0)) // stp)
+            Y = D.stft_flt_batch(xs, win, W, c0, stp, mn0=True)
+            for b in range(5):
+                assert np.array_equal(Y[b], D.stft_flt(np.ascontiguousarray(xs[b]), win, W, c0, stp, mn0=True))
+            rc, ref = O.stft_flt(np.ascontiguousarray(xs[4]), win, W, c0, stp, 512, True, False, False)
+            check_spec(O, Y[4], ref)
+    # streamed: 40 signals of 10 s (groups of signals), 3 signals of 12 M samples (ranges of frames)
+    for (B, N) in ((300 if dt == np.float32 else 150, 160000), (3, 12_000_000 if dt == np.float32 else 6_000_000)):
+        x = (rng.standard_normal((B, N)) * 0.1).astype(dt)
+        for stp in (160.0, 160.5):
+            W = int((N - 1 - 200) // stp)
+            Y = D.stft_flt_batch(x, win, W, 200.0, stp)
+            for b in (0, B - 1):
+                assert np.array_equal(Y[b], D.stft_flt(x[b], win, W, 200.0, stp))

@@ -113,6 +113,22 @@ def stft_flt_batch(x, win, W, c0=0.0, stp=160.0, mn0=False, amp=False, lg=False,
     return Y
 
 
+def stft_flt_multi(x, win, W, c0=0.0, stp=160.0, mn0=False, amp=False, lg=False, nfft=None, devices=(0,)):
+    """dsp_stft_flt_multi_s / _d: the host batch x[B, N] split over the GPUs in `devices`, one thread per GPU."""
+    x = np.ascontiguousarray(x)
+    s = _real_sfx(x.dtype)
+    win = np.ascontiguousarray(win, dtype=x.dtype)
+    B, N = x.shape
+    L = win.size
+    nfft = nextpow2(L) if nfft is None else int(nfft)
+    Y = np.empty((B, W, nfft // 2 + 1), dtype=x.dtype)
+    devs = (C.c_int * len(devices))(*devices)
+    rc = getattr(lib(), f"dsp_stft_flt_multi_{s}")(_p(Y), _p(x), _p(win), B, N, N, L, W, nfft, float(c0), float(stp), int(bool(mn0)),
+                                                   int(bool(amp)), int(bool(lg)), C.cast(devs, C.c_void_p), len(devices))
+    _check(rc, f"dsp_stft_flt_multi_{s}")
+    return Y
+
+
 def shard_range(B, rank, world):
     """dsp_shard_range: the block [lo, hi) of B signals that GPU `rank` of `world` takes."""
     lo, hi = C.c_size_t(0), C.c_size_t(0)

@@ -755,6 +755,44 @@ int stft_multi_host(const char *fn, T *Y, const T *X, const T *win, size_t B, si
     return 0;
 }
 
+// the same for the stft_flt framing (a multivariate recording over the GPUs of the node in one call)
+template <typename T>
+int stft_flt_multi_host(const char *fn, T *Y, const T *X, const T *win, size_t B, size_t N, size_t ldx, size_t L, size_t W, size_t nfft,
+                        T c0, T stp, int mn0, int amp, int lg, const int *devices, int ngpu)
+{
+    const T stp_min = (T)FLT_EPSILON;
+    if (W > N || L > N || L < 1u || N < 1u || c0 > (T)(N - 1u) || stp < stp_min || nfft < L || nfft < 2u || W == 0) {
+        FrameDesc d; std::shared_ptr<int> hold;                       // (the argument checks and their messages)
+        return flt_desc<T>(fn, 0, d, B, N, ldx, L, W, nfft, c0, stp, mn0, amp, lg, !tl_flt_intended, true, hold, stp_min);
+    }
+    if (ngpu < 1 || ngpu > MAX_DEV) { fprintf(stderr, "error in %s: ngpu must be in [1 %d]\n", fn, MAX_DEV); return 1; }
+    if (B > 1 && ldx < N) { fprintf(stderr, "error in %s: ldx must be >= N\n", fn); return 1; }
+    if (B == 0) { return 0; }
+    int ndev = 0;
+    HIPCHK(fn, hipGetDeviceCount(&ndev));
+    for (int g = 0; g < ngpu; ++g) {
+        const int dv = devices ? devices[g] : g;
+        if (dv < 0 || dv >= ndev) { fprintf(stderr, "error in %s: device %d not available\n", fn, dv); return 1; }
+    }
+    const size_t F = nfft / 2 + 1;
+    const int intended = tl_flt_intended, generic = tl_force_generic;
+    std::vector<int> rcs(ngpu, 0);
+    std::vector<std::thread> th;
+    for (int g = 0; g < ngpu; ++g) {
+        th.emplace_back([&, g] {
+            size_t lo, hi;
+            shard_range(B, (size_t)g, (size_t)ngpu, lo, hi);
+            if (hi == lo) { return; }
+            tl_device = devices ? devices[g] : g;            // thread-local settings of this worker
+            tl_flt_intended = intended; tl_force_generic = generic;
+            rcs[g] = stft_flt_host<T>(fn, Y + lo * W * F, X + lo * ldx, win, N, L, W, nfft, c0, stp, mn0, amp, lg, hi - lo, ldx);
+        });
+    }
+    for (auto &t : th) { t.join(); }
+    for (int rc : rcs) { if (rc) { return 1; } }
+    return 0;
+}
+
 // device pointers: GPU g holds its block X_dev[g] (signals [lo_g, hi_g) of the batch, dense or with ldx) and its
 // output block Y_dev[g]; if Y_all_dev (memory of devices[0] for the whole [B][W][F]) is given, every block is
 // copied there over the GPU-to-GPU links as soon as it is complete.  Returns when everything has finished.
@@ -1403,6 +1441,10 @@ int dsp_stft_multi_s(float *Y, const float *X, const float *win, const size_t B,
 { return stft_multi_host<float>("dsp_stft_multi_s", Y, X, win, B, N, ldx, L, nfft, stp, snip_edges, mn0, amp, lg, devices, ngpu); }
 int dsp_stft_multi_d(double *Y, const double *X, const double *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, const int *devices, const int ngpu)
 { return stft_multi_host<double>("dsp_stft_multi_d", Y, X, win, B, N, ldx, L, nfft, stp, snip_edges, mn0, amp, lg, devices, ngpu); }
+int dsp_stft_flt_multi_s(float *Y, const float *X, const float *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t W, const size_t nfft, const float c0, const float stp, const int mn0, const int amp, const int lg, const int *devices, const int ngpu)
+{ return stft_flt_multi_host<float>("dsp_stft_flt_multi_s", Y, X, win, B, N, ldx, L, W, nfft, c0, stp, mn0, amp, lg, devices, ngpu); }
+int dsp_stft_flt_multi_d(double *Y, const double *X, const double *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t W, const size_t nfft, const double c0, const double stp, const int mn0, const int amp, const int lg, const int *devices, const int ngpu)
+{ return stft_flt_multi_host<double>("dsp_stft_flt_multi_d", Y, X, win, B, N, ldx, L, W, nfft, c0, stp, mn0, amp, lg, devices, ngpu); }
 int dsp_stft_multi_dev_s(float *const *Y_dev, const float *const *X_dev, const float *const *win_dev, float *Y_all_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, const int *devices, const int ngpu)
 { return stft_multi_dev<float>("dsp_stft_multi_dev_s", Y_dev, X_dev, win_dev, Y_all_dev, B, N, ldx, L, nfft, stp, snip_edges, mn0, amp, lg, devices, ngpu); }
 int dsp_stft_multi_dev_d(double *const *Y_dev, const double *const *X_dev, const double *const *win_dev, double *Y_all_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, const int *devices, const int ngpu)

@@ -259,6 +259,9 @@ int dsp_stft_flt_batch_d (double *Y, const double *X, const double *win, const s
 void dsp_shard_range (const size_t B, const size_t rank, const size_t world, size_t *lo, size_t *hi);
 int dsp_stft_multi_s (float *Y, const float *X, const float *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, const int *devices, const int ngpu);
 int dsp_stft_multi_d (double *Y, const double *X, const double *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, const int *devices, const int ngpu);
+/* dsp_stft_flt_multi_s/_d: the same split for the stft_flt framing, host pointers as dsp_stft_flt_batch_s/_d. */
+int dsp_stft_flt_multi_s (float *Y, const float *X, const float *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t W, const size_t nfft, const float c0, const float stp, const int mn0, const int amp, const int lg, const int *devices, const int ngpu);
+int dsp_stft_flt_multi_d (double *Y, const double *X, const double *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t W, const size_t nfft, const double c0, const double stp, const int mn0, const int amp, const int lg, const int *devices, const int ngpu);
 int dsp_stft_multi_dev_s (float *const *Y_dev, const float *const *X_dev, const float *const *win_dev, float *Y_all_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, const int *devices, const int ngpu);
 int dsp_stft_multi_dev_d (double *const *Y_dev, const double *const *X_dev, const double *const *win_dev, double *Y_all_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, const int *devices, const int ngpu);
 

@@ -634,6 +634,13 @@ def test_multi_gpu_entry_points_on_one_device(O, D):
         assert np.array_equal(torch.cat(ys).cpu().numpy(), ref)
     rc, Yref = O.stft(x[4], win, 160, 512, 0, 1)
     check_spec(O, ref[4], Yref)
+    # the stft_flt framing over the same device lists (integral hop, and a table of frame starts)
+    x = np.stack([signal(950 + b, 24000, dt) for b in range(7)])
+    for stp in (160.0, 133.37):
+        W = int((24000 - 1 - 200) // stp)
+        ref = D.stft_flt_batch(x, win, W, 200.0, stp, lg=True)
+        for devs in ([0, 0, 0], [0] * 9, [0]):
+            assert np.array_equal(D.stft_flt_multi(x, win, W, 200.0, stp, lg=True, devices=devs), ref)
 
 
 def test_nan_stays_in_its_own_frames(O, D):

@@ -36,6 +36,7 @@ SIGNATURES = {
     "fft_fftw_s": (_int, _R2HC), "fft_fftw_d": (_int, _R2HC), "fft_fftw_c": (_int, _R2HC), "fft_fftw_z": (_int, _R2HC),
     "dsp_stft_num_frames": (_sz, [_sz, _sz, _sz, _int]),
     "dsp_set_device": (_int, [_int]),
+    "dsp_stft_release_buffers": (_int, []),
     "dsp_stft_flt_set_mode": (_int, [_int]),
     "dsp_stft_batch_dev_s": (_int, _BDEV), "dsp_stft_batch_dev_d": (_int, _BDEV),
     "dsp_stft_batch_dev_noalloc_s": (_int, _BDEV),

@@ -1358,6 +1358,40 @@ int dsp_set_device(const int device)
     return 0;
 }
 
+// Gives back what the host-pointer entry points keep between calls on the calling thread's device: the device
+// workspace, the pinned stages and their device twins, and the cached stft_flt frame-start tables.  (The twiddle
+// tables, a few KB per transform length, and the streams stay.)  Calls in progress on other threads finish first.
+int dsp_stft_release_buffers(void)
+{
+    const char *fn = "dsp_stft_release_buffers";
+    int dev;
+    if (use_device(fn, dev)) { return 1; }
+    DevState &st = g_dev[dev];
+    std::list<std::pair<FltKey, FltFraming>> dropped;          // tables are freed once no call holds them
+    {
+        std::lock_guard<std::mutex> lk(st.mu);
+        dropped.swap(st.flt);
+    }
+    dropped.clear();
+    tl_flt_htbl.reset();
+    std::lock_guard<std::mutex> lk(st.ws_mu);
+    int rc = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (st.ws[i] && hipFree(st.ws[i]) != hipSuccess) { rc = 1; }
+        st.ws[i] = nullptr; st.cap[i] = 0;
+    }
+    for (int i = 0; i < DevState::SLOTS; ++i) {
+        if (st.pin_in[i] && hipHostFree(st.pin_in[i]) != hipSuccess) { rc = 1; }
+        if (st.pin_out[i] && hipHostFree(st.pin_out[i]) != hipSuccess) { rc = 1; }
+        if (st.dev_in[i] && hipFree(st.dev_in[i]) != hipSuccess) { rc = 1; }
+        if (st.dev_out[i] && hipFree(st.dev_out[i]) != hipSuccess) { rc = 1; }
+        st.pin_in[i] = st.pin_out[i] = st.dev_in[i] = st.dev_out[i] = nullptr;
+    }
+    st.cap_in = st.cap_out = 0;
+    if (rc) { fprintf(stderr, "error in %s: hip call failed (free)\n", fn); }
+    return rc;
+}
+
 int dsp_stft_flt_set_mode(const int intended) { tl_flt_intended = intended != 0; return 0; }
 int dsp_stft_force_generic(const int on) { tl_force_generic = on != 0; return 0; }
 

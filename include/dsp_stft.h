@@ -189,6 +189,10 @@ size_t dsp_stft_num_frames (const size_t N, const size_t L, const size_t stp, co
  * dsp_stft_flt_set_mode and dsp_stft_force_generic are settings of the CALLING THREAD: threads that want
  * different devices or framings do not disturb each other, and a new thread starts with the defaults. */
 int dsp_set_device (const int device);
+/* Frees what the host-pointer entry points keep between calls on the calling thread's device: the device workspace
+ * (as large as the largest unstreamed call so far), the pinned stages of the streamed path and the cached stft_flt
+ * frame tables.  For long-running hosts; the next call allocates again what it needs. */
+int dsp_stft_release_buffers (void);
 
 /* stft_flt framing: 0 (default) = what the reference's code computes: once frames stop overlapping
  * the left edge every frame is read `shift` samples early, shift = start of the first frame whose

@@ -1300,3 +1300,23 @@ def test_stft_flt_host_batch(O, D, dt):
             Y = D.stft_flt_batch(x, win, W, 200.0, stp)
             for b in (0, B - 1):
                 assert np.array_equal(Y[b], D.stft_flt(x[b], win, W, 200.0, stp))
+
+
+def test_release_buffers_between_host_calls(O, D):
+    """dsp_stft_release_buffers gives back the workspace, the pinned stages and the cached stft_flt tables of the device;
+    the calls after it allocate again and return the same bits (an unstreamed call, a streamed batch, a table framing)."""
+    import torch
+    from dsp_amd._lib import lib
+    rng = np.random.default_rng(8)
+    x = (rng.standard_normal((70, 160000)) * 0.1).astype(np.float32)
+    win = D.hann(400, np.float32)
+    W = int((160000 - 1 - 200) // 160.5)
+    before = (D.stft(x[0], win, 160), D.stft_batch(x, win, 160), D.stft_flt(x[1], win, W, 200.0, 160.5))
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    assert lib().dsp_stft_release_buffers() == 0
+    assert torch.cuda.mem_get_info()[0] > free0                  # device memory came back
+    after = (D.stft(x[0], win, 160), D.stft_batch(x, win, 160), D.stft_flt(x[1], win, W, 200.0, 160.5))
+    for a, b in zip(before, after):
+        assert np.array_equal(a, b)
+    assert lib().dsp_stft_release_buffers() == 0 and lib().dsp_stft_release_buffers() == 0   # idempotent

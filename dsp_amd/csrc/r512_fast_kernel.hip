@@ -111,6 +111,9 @@ __device__ unsigned long long g_r512f_stamps[8192 * 8];
 #ifndef R512F_TWD_AHEAD_F64
 #define R512F_TWD_AHEAD_F64 2   // the same for double (registers are short there)
 #endif
+#ifndef R512F_CYCLIC
+#define R512F_CYCLIC 0          // 1: block-cyclic deal of the steps over the 8 groups of workgroups (measured: the same on the 1.7 GB benchmark batch, 2.5 % slower on 13.7 GB)
+#endif
 #ifndef R512F_NOLOAD
 #define R512F_NOLOAD 0          // diagnostic builds: 1 = the span loads are compiled out
 #endif
@@ -290,8 +293,14 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
     // the same L1 or L2) instead of thousands of separate streams.  Draw t of a workgroup is step t % 8 of
     // its round t / 8: the wave that is ready first takes it.
     const int xcd = blockIdx.x & 7, nwg_x = gridDim.x >> 3;
+#if R512F_CYCLIC
+    // (experiment: the groups take turns, block by block, through ONE moving window of the batch instead of 8 ranges)
+    const int s_hi = a.steps;
+    const int round = 8 * nwg_x * 8, first = xcd * nwg_x * 8 + (blockIdx.x >> 3) * 8;
+#else
     const int s_lo = (int)((long long)a.steps * xcd / 8), s_hi = (int)((long long)a.steps * (xcd + 1) / 8);
     const int round = nwg_x * 8, first = s_lo + (blockIdx.x >> 3) * 8;
+#endif
     int sid = first + (wv >> 3) * round + (wv & 7);      // draw number wv
     if (sid >= s_hi) { return; }
     int b = sid / a.sps;
@@ -617,11 +626,10 @@ static hipError_t launch_stft_r512_fast_one(T *Y, const T *X, const T *win, cons
 
 // Very large batches go as several launches of whole signals, one behind the other in the stream: measured on 64 float64
 // channels of one hour (77 GB of input and output) one launch takes 15.4 ms, launches of 8 channels 14.6 ms and of 4
-// channels 14.4 ms; on 8192 ten-second utterances (13.7 GB) 2.66 against 2.60 ms in launches of 2048.  (The 8 ranges
-// into which a launch cuts its steps, one per group of workgroups that share an L2, then lie closer together.)  Below
-// R512F_SPLIT_ABOVE bytes of input and output a launch stays whole: the 1.7 GB benchmark batch loses 3 % when halved.
+// channels 14.4 ms.  Below R512F_SPLIT_ABOVE bytes of input and output a launch stays whole: 8192 ten-second utterances
+// (13.7 GB) measured the same either way (2.62 ms), the 1.7 GB benchmark batch loses 3 % when halved.
 #ifndef R512F_SPLIT_ABOVE
-#define R512F_SPLIT_ABOVE (10ull << 30)
+#define R512F_SPLIT_ABOVE (16ull << 30)
 #endif
 #ifndef R512F_SPLIT_BYTES
 #define R512F_SPLIT_BYTES (5ull << 30)

@@ -40,6 +40,8 @@ SIGNATURES = {
     "dsp_stft_flt_set_mode": (_int, [_int]),
     "dsp_stft_batch_dev_s": (_int, _BDEV), "dsp_stft_batch_dev_d": (_int, _BDEV),
     "dsp_stft_batch_dev_noalloc_s": (_int, _BDEV),
+    "dsp_stft_cplx_batch_dev_s": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _int, _int, _vp]),
+    "dsp_stft_cplx_batch_dev_d": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _int, _int, _vp]),
     "dsp_shard_range": (None, [_sz, _sz, _sz, _vp, _vp]),
     "dsp_stft_multi_s": (_int, _BHOST + [_vp, _int]), "dsp_stft_multi_d": (_int, _BHOST + [_vp, _int]),
     "dsp_stft_multi_dev_s": (_int, [_vp, _vp, _vp, _vp] + _BDEV[3:-1] + [_vp, _int]),

@@ -482,6 +482,35 @@ def stft_dev(x, win, stp=160, snip_edges=False, mn0=False, amp=False, lg=False, 
     return out
 
 
+def stft_cplx_dev(x, win, stp=160, snip_edges=False, sc=False, nfft=None, out=None):
+    """dsp_stft_cplx_batch_dev_s / _d: the complex spectrogram Y[B, W, F] (torch complex64 / complex128) of the device
+    tensor x[B, N] (or x[N]), enqueued on the current stream."""
+    import torch
+    single = x.dim() == 1
+    if single:
+        x = x[None, :]
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    s = _torch_sfx(x)
+    win = win.to(device=x.device, dtype=x.dtype).contiguous()
+    B, N = x.shape
+    L = win.numel()
+    nfft = nextpow2(L) if nfft is None else int(nfft)
+    W = num_frames(N, L, stp, snip_edges)
+    cdt = torch.complex64 if x.dtype == torch.float32 else torch.complex128
+    if out is None:
+        out = torch.empty((B, W, nfft // 2 + 1), dtype=cdt, device=x.device)
+    else:
+        _check_out(out, (B, W, nfft // 2 + 1), out, "stft_cplx_dev")
+        if out.dtype != cdt or out.device != x.device:
+            raise ValueError("stft_cplx_dev: out must be a complex tensor of x's precision on x's device")
+    ldx = x.stride(0) if B > 1 else N
+    rc = getattr(lib(), f"dsp_stft_cplx_batch_dev_{s}")(C.c_void_p(out.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(win.data_ptr()),
+                                                        B, N, ldx, L, nfft, stp, int(bool(snip_edges)), int(bool(sc)), _stream_ptr(x))
+    _check(rc, f"dsp_stft_cplx_batch_dev_{s}")
+    return out[0] if single else out
+
+
 def stft_pc_dev(x, win, p, preg=0.0, stp=160, snip_edges=False, mn0=False, amp=False, lg=False, nfft=None, out=None):
     """dsp_stft_pc_batch_dev_s / _d: stft_dev with pow_compress(., p, preg) fused into the store."""
     import torch

@@ -1185,10 +1185,59 @@ int c2c_host(const char *fn, T *Y, const T *X, size_t R, size_t C, size_t S, siz
     return 0;
 }
 
+// The complex spectrogram: framing and windowing as stft (reference c/window_univar.c:41-89), then the real FFT of every
+// frame as fft_fftw_r2hc gives it (c/fft.fftw.r2hc.c:69-78: nfft/2+1 interleaved complex values, imaginary parts of the
+// first and last zero; sc: every value times 1/sqrt(2 nfft)).  Device pointers, enqueued on `stream`.  nfft 512 with a hop
+// of at most 512 runs on the fused 512-point kernel; everything else through the unfused kernels with a temporary for the
+// frames that is allocated and freed in the stream's order.
+template <typename T>
+int stft_cplx_dev(const char *fn, T *Yd, const T *Xd, const T *wd, size_t B, size_t N, size_t ldx, size_t L, size_t nfft, size_t stp,
+                  int snip_edges, int sc, void *stream)
+{
+    FrameDesc d; size_t W;
+    if (stft_desc(fn, d, B, N, ldx, L, nfft, stp, snip_edges, 0, 0, 0, W)) { return 1; }
+    if (W == 0 || B == 0) { return 0; }
+    if (B > 1 && ldx < N) { fprintf(stderr, "error in %s: ldx must be >= N\n", fn); return 1; }
+    if (!Yd || !Xd || !wd) { fprintf(stderr, "error in %s: null device pointer\n", fn); return 1; }
+    int dev;
+    if (use_device(fn, dev)) { return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    const double scale = sc ? 1.0 / sqrt((double)(2u * nfft)) : 1.0;
+    const int pow2 = is_pow2(nfft) ? 1 : 0;
+    const T *tw = nullptr;
+    if (nfft == 512 && !tl_force_generic && r512_fast_cplx_supported(d)) {
+        if (get_twiddles<T>(fn, dev, nfft, 0, tw)) { return 1; }
+        HIPCHK(fn, launch_stft_r512_fast_cplx<T>(Yd, Xd, wd, tw, d, scale, s));
+        return 0;
+    }
+    if ((pow2 ? nfft : L) * sizeof(T) > LDS_LIMIT) { fprintf(stderr, "error in %s: nfft too large (limit %zu)\n", fn, LDS_LIMIT / sizeof(T)); return 1; }
+    if (get_twiddles<T>(fn, dev, nfft, pow2 ? 0 : 1, tw)) { return 1; }
+    void *frames = nullptr;
+    HIPCHK(fn, hipMallocAsync(&frames, B * W * L * sizeof(T), s));
+    int rc = 0;
+    for (size_t b = 0; b < B && !rc; ++b) {
+        if (hipError_t e = launch_frames<T>((T *)frames + b * W * L, Xd + b * ldx, wd, d, 1, s); e != hipSuccess) {
+            fprintf(stderr, "error in %s: hip call failed (framing): %s\n", fn, hipGetErrorString(e)); rc = 1;
+        }
+    }
+    if (!rc) {
+        if (hipError_t e = launch_r2hc<T>(Yd, (const T *)frames, tw, B * W, 1, L, nfft, pow2, (T)scale, s); e != hipSuccess) {
+            fprintf(stderr, "error in %s: hip call failed (transform): %s\n", fn, hipGetErrorString(e)); rc = 1;
+        }
+    }
+    HIPCHK(fn, hipFreeAsync(frames, s));
+    return rc;
+}
+
 }  // namespace
 
 // ================================================================================================
 extern "C" {
+
+int dsp_stft_cplx_batch_dev_s(float *Y_dev, const float *X_dev, const float *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int sc, void *stream)
+{ return stft_cplx_dev<float>("dsp_stft_cplx_batch_dev_s", Y_dev, X_dev, win_dev, B, N, ldx, L, nfft, stp, snip_edges, sc, stream); }
+int dsp_stft_cplx_batch_dev_d(double *Y_dev, const double *X_dev, const double *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int sc, void *stream)
+{ return stft_cplx_dev<double>("dsp_stft_cplx_batch_dev_d", Y_dev, X_dev, win_dev, B, N, ldx, L, nfft, stp, snip_edges, sc, stream); }
 
 int stft_s(float *Y, const float *X1, const float *X2, const size_t N, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg)
 { return stft_host<float>("stft_s", Y, X1, X2, 1, N, N, L, nfft, stp, snip_edges, mn0, amp, lg); }

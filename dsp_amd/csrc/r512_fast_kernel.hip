@@ -39,6 +39,7 @@ struct R512FastArgs {
     int steps;            // B * sps
     const int *tbl;       // table form: start of frame w at tbl[2 w] (frames need not be equally spaced)
     int all16;            // every step has 4 frames and its block of rows is 16-byte aligned
+    double cscale;        // complex form: factor on every output value (1, or 1 / sqrt(2 nfft))
 };
 
 constexpr int R512F_WAVE_ELEMS = 4 * R512_EXF * 2;   // T elements of a wave's exchange tile (>= 2048: the longest span)
@@ -134,7 +135,10 @@ __device__ unsigned long long g_r512f_stamps[8192 * 8];
 #endif
 
 
-template <typename T, int NR, bool MN0, bool EPI, int WIDE, bool TBL, bool RING>
+// CPLX: the rows are the complex spectra themselves (257 interleaved (re, im) pairs per frame, imag(DC) = imag(Nyquist) = 0:
+// what window_univar followed by fft_fftw_r2hc gives, reference c/window_univar.c:41-89, c/fft.fftw.r2hc.c:69-78) instead
+// of their powers; everything up to the split is the same.
+template <typename T, int NR, bool MN0, bool EPI, int WIDE, bool TBL, bool RING, bool CPLX = false>
 __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *__restrict__ Y, const T *__restrict__ X,
                                                                              const T *__restrict__ win, const T *__restrict__ tw,
                                                                              const R512FastArgs a)
@@ -151,6 +155,9 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
     // samples): there they are read from an LDS table
     constexpr bool TWREG = !R512F_TW_LDS && !(R512F_TW_LDS_F64 && sizeof(T) == 8) && !(R512F_TWLDS_SEL);
     constexpr int M = 256, F = 257, NWV = R512F_WAVES;
+    constexpr int ROWF = CPLX ? 2 * F : F;                 // T elements of an output row
+    constexpr int BLK = 4 * ROWF;                          // ... of a step's block of rows
+    static_assert(BLK <= R512F_WAVE_ELEMS, "the staged rows of a step fit the wave's tile");
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
     int b = sid / a.sps;
     int w = (sid - b * a.sps) * 4;
     const T *xb = X + (long long)b * a.ldx;
-    T *yb = Y + (long long)b * a.W * F;
+    T *yb = Y + (long long)b * a.W * ROWF;
 
     // the wave's next step, from its latest draw
     const unsigned cnt_addr = ring_lds_addr(ticket);
@@ -323,7 +330,7 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
             const int nb = nsid / a.sps;
             nw = (nsid - nb * a.sps) * 4;
             nxb = X + (long long)nb * a.ldx;
-            nyb = Y + (long long)nb * a.W * F;
+            nyb = Y + (long long)nb * a.W * ROWF;
         }
     };
 
@@ -365,10 +372,10 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
             // The span of this step was asked for in the middle of the last one.  Memory operations complete in
             // issue order: behind its NV loads lie that step's row stores, so waiting until that many are
             // outstanding leaves the stores in flight.  (First step: nothing lies behind the span.)
-            constexpr int K16 = 1028 / VEC / 64 + 1;
+            constexpr int K16 = BLK / VEC / 64 + 1;
             if (first_step) { ring_wait_vm<0>(); }
             else if (a.all16) { ring_wait_vm<K16>(); }
-            else { ring_wait_vm<17>(); }
+            else { ring_wait_vm<BLK / 64 + 1>(); }
             first_step = false;
             wave_sync();
             R512F_STAMP(7);
@@ -481,47 +488,73 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
         // (register (16 - k2) % 16 of lane 0 itself when j == 0): one row_mirror + row_ror:1 DPP move.
         // With A = Z_k + conj Z_{256-k}, B = Z_k - conj Z_{256-k}, T = -i W512^k B:
         // |X_k|^2 = |A + T|^2 and |X_{256-k}|^2 = |A - T|^2.
-        T pw[16];                                          // pw[k2] = P[k], pw[8 + k2] = P[256 - k]
-        T p128 = T(4) * cx_norm<T>(zz[slot16(8)]);         // lane j == 0 only
-#pragma unroll
-        for (int k2 = 0; k2 < 8; ++k2) {
-            const C z = zz[slot16(k2)];
-            // (lane 0 is its own partner: the move hands it its own register 15 - k2, which the select replaces; a
-            // select in front of the move would be turned into a select of the register INDEX, a 16-way chain)
-            const C own = zz[slot16((16 - k2) & 15)], oth = zz[slot16(15 - k2)];
-            const T px = dpp_partner16(oth.x), py = dpp_partner16(oth.y);
-            const C m = C{(j == 0) ? own.x : px, (j == 0) ? own.y : py};
-            const C A = cx_add_conj<T>(z, m), B = cx_sub_conj<T>(z, m);
-            const C Tw = cx_mul<T>(B, ow[k2]);
-            pw[k2] = cx_norm<T>(A + Tw);
-            pw[8 + k2] = cx_norm<T>(A - Tw);
-        }
-        if (EPI) {
-            power_epilogue_n(pw, a.epi);
-            p128 = power_epilogue(p128, a.epi);
-        }
-        wave_sync();                                       // every lane has read its tile row: reuse the region
-        {
-            T *pf = xs + f * F + j;                        // 4 rows of 257 values, as they lie in Y
+        if constexpr (CPLX) {
+            // X_k = A + T, X_{256-k} = conj(A - T); bin 128 is 2 conj Z_128 (lane j == 0), bins 0 and 256 come out real
+            const T sc = (T)a.cscale;
+            const C z8 = zz[slot16(8)];
+            wave_sync();                                   // every lane has read its tile row (into zz): reuse the region
+            T2 *pf = reinterpret_cast<T2 *>(xs) + f * F + j;       // 4 rows of 257 complex values, as they lie in Y
 #pragma unroll
             for (int k2 = 0; k2 < 8; ++k2) {
-                pf[16 * k2] = pw[k2];                      // bin j + 16 k2
-                pf[M - 2 * j - 16 * k2] = pw[8 + k2];      // bin 256 - (j + 16 k2)
+                const C z = zz[slot16(k2)];
+                const C own = zz[slot16((16 - k2) & 15)], oth = zz[slot16(15 - k2)];
+                const T px = dpp_partner16(oth.x), py = dpp_partner16(oth.y);
+                const C m = C{(j == 0) ? own.x : px, (j == 0) ? own.y : py};
+                const C A = cx_add_conj<T>(z, m), B = cx_sub_conj<T>(z, m);
+                const C Tw = cx_mul<T>(B, ow[k2]);
+                const C u = A + Tw, v = A - Tw;
+                // (each value goes to the staging area as soon as it exists: held back, the 32 of them do not fit the registers)
+                T2 o; o.x = sc * u.x; o.y = (j == 0 && k2 == 0) ? T(0) : sc * u.y;           // imag(DC) = 0
+                pf[16 * k2] = o;
+                T2 q; q.x = sc * v.x; q.y = (j == 0 && k2 == 0) ? T(0) : -sc * v.y;          // imag(Nyquist) = 0
+                pf[M - 2 * j - 16 * k2] = q;
             }
-            if (j == 0) { pf[128] = p128; }
+            if (j == 0) { T2 o; o.x = T(2) * sc * z8.x; o.y = T(-2) * sc * z8.y; pf[128] = o; }
+            wave_sync();
+        } else {
+            T pw[16];                                          // pw[k2] = P[k], pw[8 + k2] = P[256 - k]
+            T p128 = T(4) * cx_norm<T>(zz[slot16(8)]);         // lane j == 0 only
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) {
+                const C z = zz[slot16(k2)];
+                // (lane 0 is its own partner: the move hands it its own register 15 - k2, which the select replaces; a
+                // select in front of the move would be turned into a select of the register INDEX, a 16-way chain)
+                const C own = zz[slot16((16 - k2) & 15)], oth = zz[slot16(15 - k2)];
+                const T px = dpp_partner16(oth.x), py = dpp_partner16(oth.y);
+                const C m = C{(j == 0) ? own.x : px, (j == 0) ? own.y : py};
+                const C A = cx_add_conj<T>(z, m), B = cx_sub_conj<T>(z, m);
+                const C Tw = cx_mul<T>(B, ow[k2]);
+                pw[k2] = cx_norm<T>(A + Tw);
+                pw[8 + k2] = cx_norm<T>(A - Tw);
+            }
+            if (EPI) {
+                power_epilogue_n(pw, a.epi);
+                p128 = power_epilogue(p128, a.epi);
+            }
+            wave_sync();                                       // every lane has read its tile row: reuse the region
+            {
+                T *pf = xs + f * F + j;                        // 4 rows of 257 values, as they lie in Y
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) {
+                    pf[16 * k2] = pw[k2];                      // bin j + 16 k2
+                    pf[M - 2 * j - 16 * k2] = pw[8 + k2];      // bin 256 - (j + 16 k2)
+                }
+                if (j == 0) { pf[128] = p128; }
+            }
+            wave_sync();
         }
-        wave_sync();
         R512F_STAMP(3);
 
         // ---- store the rows of the step: 1028 consecutive values of Y (fewer at the end of a signal:
         // the index is clamped, so the surplus lanes rewrite the last value with itself and the number
         // of store instructions per step stays fixed)
         {
-            T *yblk = yb + (unsigned)(w * F);
+            T *yblk = yb + (unsigned)(w * ROWF);
 #if R512F_ST4
             if (RING ? a.all16 != 0 : (a.W - w >= 4 && (reinterpret_cast<uintptr_t>(yblk) & 15) == 0)) {
-                // 1028 values = 257 16-byte vectors (float) / 514 (double): whole-vector wave stores
-                constexpr int NVEC = 1028 / VEC, FULLI = NVEC / 64;
+                // 1028 values = 257 16-byte vectors (float) / 514 (double), twice that for complex rows: whole-vector wave stores
+                constexpr int NVEC = BLK / VEC, FULLI = NVEC / 64;
+                static_assert(((NVEC - FULLI * 64) & (NVEC - FULLI * 64 - 1)) == 0, "the last store's lanes wrap by a mask");
 #pragma unroll
                 for (int i = 0; i <= FULLI; ++i) {
                     const int idx = (i < FULLI) ? lane + 64 * i : FULLI * 64 + (lane & (NVEC - FULLI * 64 - 1));
@@ -543,16 +576,17 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
             } else
 #endif
             if (a.W - w >= 4) {
+                constexpr int NS = BLK / 64, TAIL = BLK - NS * 64;     // 16 + 4 values (complex rows: 32 + 8)
 #pragma unroll
-                for (int i = 0; i < 17; ++i) {
-                    // the 17th instruction carries the last 4 values; its other lanes repeat value 1027
-                    const int idx = (i < 16) ? lane + 64 * i : 1024 + (lane & 3);
+                for (int i = 0; i <= NS; ++i) {
+                    // the last instruction carries the last TAIL values; its other lanes repeat them
+                    const int idx = (i < NS) ? lane + 64 * i : NS * 64 + (lane & (TAIL - 1));
                     R512F_ST(yblk + idx, xs[idx]);
                 }
             } else {
-                const int last = (a.W - w) * F - 1;
+                const int last = (a.W - w) * ROWF - 1;
 #pragma unroll
-                for (int i = 0; i < 17; ++i) {
+                for (int i = 0; i <= BLK / 64; ++i) {
                     const int idx = min(lane + 64 * i, last);
                     R512F_ST(yblk + idx, xs[idx]);
                 }
@@ -607,17 +641,17 @@ bool r512_fast_supported(const FrameDesc &d)
            d.rd_shift >= 0 && d.rd_shift < (1ll << 30);
 }
 
-template <typename T, int NR, bool MN0, bool EPI, int WIDE, bool TBL, bool RING>
+template <typename T, int NR, bool MN0, bool EPI, int WIDE, bool TBL, bool RING, bool CPLX = false>
 static hipError_t launch_fast_inst(T *Y, const T *X, const T *win, const T *tw, const R512FastArgs &a, hipStream_t s)
 {
     constexpr int SPAN = WIDE == 2 ? 2048 : WIDE ? 1280 : 1024;
     const size_t lds = (R512F_WAVES * ((size_t)R512F_WAVE_ELEMS + (RING ? SPAN : 0)) + 512 + 512) * sizeof(T) + 1024 + 16;
     static LdsGrant grant;
-    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r512_fast_kernel<T, NR, MN0, EPI, WIDE, TBL, RING>), lds, grant); e != hipSuccess) { return e; }
+    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r512_fast_kernel<T, NR, MN0, EPI, WIDE, TBL, RING, CPLX>), lds, grant); e != hipSuccess) { return e; }
     long long grid = ((long long)a.steps + 7) / 8;
     if (grid > 256) { grid = 256; }                     // one 8-wave workgroup per CU
     grid = (grid + 7) & ~7ll;                           // whole groups of 8 workgroups (one per XCD)
-    hipLaunchKernelGGL((stft_r512_fast_kernel<T, NR, MN0, EPI, WIDE, TBL, RING>), dim3((unsigned)grid), dim3(64 * R512F_WAVES), lds, s, Y, X, win, tw, a);
+    hipLaunchKernelGGL((stft_r512_fast_kernel<T, NR, MN0, EPI, WIDE, TBL, RING, CPLX>), dim3((unsigned)grid), dim3(64 * R512F_WAVES), lds, s, Y, X, win, tw, a);
     return hipGetLastError();
 }
 
@@ -715,6 +749,41 @@ static hipError_t launch_stft_r512_fast_one(T *Y, const T *X, const T *win, cons
 #undef DSP_R512T
 #undef DSP_R512U
 }
+
+// The complex form: Y[b][w][257] interleaved (re, im) pairs times `scale`; equally spaced frames, no mean removal.
+bool r512_fast_cplx_supported(const FrameDesc &d)
+{
+    return r512_fast_supported(d) && d.tbl == nullptr && !d.mn0 && !d.epi.any() && (long long)d.W * 514 < (1ll << 30);
+}
+
+template <typename T>
+hipError_t launch_stft_r512_fast_cplx(T *Y, const T *X, const T *win, const T *tw, const FrameDesc &d, double scale, hipStream_t s)
+{
+#if R512F_MINIMAL
+    return hipErrorInvalidValue;
+#else
+    R512FastArgs a{};
+    a.ldx = d.ldx; a.N = (int)d.N; a.L = d.L; a.W = d.W; a.stp = d.stp; a.ss0 = (int)d.ss0;
+    a.rd_shift = (int)d.rd_shift; a.edge = d.edge; a.epi = d.epi;
+    a.sps = (d.W + 3) / 4;
+    a.steps = d.B * a.sps;
+    a.tbl = nullptr;
+    a.cscale = scale;
+    a.all16 = (d.W % 4 == 0) && (reinterpret_cast<uintptr_t>(Y) % 16 == 0);
+    constexpr bool RING = sizeof(T) == 4 && R512F_RING_F32;
+    const bool wide = 3 * d.stp + 512 > 1024 || (d.stp & 1);
+    const bool nr13 = d.L > 384 && d.L <= 416;
+    if (3 * d.stp + 512 > 1280) { return launch_fast_inst<T, 16, false, false, 2, false, RING, true>(Y, X, win, tw, a, s); }
+    if (wide) {
+        return nr13 ? launch_fast_inst<T, 13, false, false, 1, false, RING, true>(Y, X, win, tw, a, s)
+                    : launch_fast_inst<T, 16, false, false, 1, false, RING, true>(Y, X, win, tw, a, s);
+    }
+    return nr13 ? launch_fast_inst<T, 13, false, false, 0, false, RING, true>(Y, X, win, tw, a, s)
+                : launch_fast_inst<T, 16, false, false, 0, false, RING, true>(Y, X, win, tw, a, s);
+#endif
+}
+template hipError_t launch_stft_r512_fast_cplx<float>(float *, const float *, const float *, const float *, const FrameDesc &, double, hipStream_t);
+template hipError_t launch_stft_r512_fast_cplx<double>(double *, const double *, const double *, const double *, const FrameDesc &, double, hipStream_t);
 
 template hipError_t launch_stft_r512_fast<float>(float *, const float *, const float *, const float *, const FrameDesc &, hipStream_t);
 template hipError_t launch_stft_r512_fast<double>(double *, const double *, const double *, const double *, const FrameDesc &, hipStream_t);

@@ -217,6 +217,8 @@ hipError_t launch_stft_r256(float *Y, const float *X, const float *win, const fl
 template <typename T> bool wave_fft_supported(const FrameDesc &d);
 template <typename T> hipError_t launch_stft_wave(T *Y, const T *X, const T *win, const T *tw, const FrameDesc &d, hipStream_t s);
 template <typename T> hipError_t launch_stft_r512_fast(T *Y, const T *X, const T *win, const T *tw, const FrameDesc &d, hipStream_t s);
+bool r512_fast_cplx_supported(const FrameDesc &d);
+template <typename T> hipError_t launch_stft_r512_fast_cplx(T *Y, const T *X, const T *win, const T *tw, const FrameDesc &d, double scale, hipStream_t s);
 
 // ---- unfused kernels (unfused_kernels.hip) ----------------------------------------------------
 enum WindowKind { WIN_HANN = 0, WIN_HAMMING, WIN_POVEY, WIN_BLACKMANHARRIS, WIN_BLACKMAN, WIN_BARTLETT, WIN_TRIANGULAR,

@@ -1320,3 +1320,41 @@ def test_release_buffers_between_host_calls(O, D):
     for a, b in zip(before, after):
         assert np.array_equal(a, b)
     assert lib().dsp_stft_release_buffers() == 0 and lib().dsp_stft_release_buffers() == 0   # idempotent
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_complex_spectrogram(O, D, dt):
+    """dsp_stft_cplx_batch_dev_s/_d: frames times window, then the real FFT of each frame (what window_univar followed
+    by fft_fftw_r2hc gives, c/window_univar.c:41-89, c/fft.fftw.r2hc.c:69-78), against the oracle's framing and r2hc
+    restatements applied one after the other; its squared magnitude equals the power spectrogram of stft on the same
+    input.  Shapes of the fused 512-point kernel (all span forms, odd hop, 13- and 16-row windows, blocks of rows off
+    16-byte boundaries, a batch) and of the unfused fallback (other nfft, hop above 512, a transform length that is no
+    power of two); the 1/sqrt(2 nfft) scaling."""
+    import torch
+    tol = TOL[np.dtype(dt)]
+    rng = np.random.default_rng(41)
+    cases = [(3, 16000, 400, 160, 512, False), (2, 16001, 400, 161, 512, False), (2, 9000, 512, 256, 512, False), (1, 20000, 300, 400, 512, True),
+             (2, 7000, 400, 200, 512, False), (1, 5000, 512, 128, 512, False), (5, 1603, 400, 160, 512, False),
+             (2, 6000, 256, 64, 256, False), (1, 9000, 1024, 256, 1024, False), (1, 9000, 400, 600, 512, False), (2, 3000, 100, 50, 120, False)]
+    for (B, N, L, hop, nfft, snip) in cases:
+        x = (rng.standard_normal((B, N)) * 0.1).astype(dt)
+        win = D.povey(L, dt) if L > 1 else np.ones(1, dt)
+        xd, wd = torch.from_numpy(x).cuda(), torch.from_numpy(win).cuda()
+        for sc in (False, True):
+            Y = D.stft_cplx_dev(xd, wd, hop, snip_edges=snip, sc=sc, nfft=nfft)
+            P = D.stft_dev(xd, wd, hop, snip_edges=snip, nfft=nfft)
+            torch.cuda.synchronize()
+            Yh, Ph = Y.cpu().numpy(), P.cpu().numpy()
+            k = (1.0 / np.sqrt(2.0 * nfft)) if sc else 1.0
+            for b in range(B):
+                rc, fr = O.frame_univar(x[b], L, hop, snip)
+                assert rc == 0
+                rc, ref = O.fft_r2hc(np.ascontiguousarray(fr * win[None, :]), 1, nfft, False, sc)
+                assert rc == 0 and Yh[b].shape == ref.shape, (B, N, L, hop, nfft)
+                # per frame, relative to the frame's largest bin: amplitudes carry half the digits of the power bound
+                scale = np.abs(ref).max(axis=1, keepdims=True)
+                err = float((np.abs(Yh[b] - ref) / np.maximum(scale, 1e-300)).max())
+                assert err <= (3e-6 if dt == np.float32 else 1e-14), ((B, N, L, hop, nfft, snip, sc), err)
+                assert np.all(Yh[b][:, 0].imag == 0) and np.all(Yh[b][:, -1].imag == 0)
+                mag2 = (Yh[b].real.astype(np.float64) ** 2 + Yh[b].imag.astype(np.float64) ** 2) / (k * k)
+                assert O.normalised_err(mag2.astype(dt), Ph[b]) <= tol

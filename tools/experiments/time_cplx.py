@@ -1,0 +1,26 @@
+"""Launch time of the complex spectrogram (dsp_stft_cplx_batch_dev) on the benchmark shapes, beside torch.stft on the same input."""
+import sys
+sys.path.insert(0, '.')
+import numpy as np, torch, dsp_amd
+def t(f, n=50):
+    for _ in range(n // 2): f()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): f()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+for (dt, B, N, L, hop) in ((torch.float32, 1024, 160000, 400, 160), (torch.float64, 512, 160000, 400, 160), (torch.float32, 1024, 160000, 512, 256)):
+    x = torch.randn((B, N), device='cuda', dtype=dt) * 0.1
+    win = torch.from_numpy(dsp_amd.hann(L, np.float32 if dt == torch.float32 else np.float64)).cuda()
+    y = dsp_amd.stft_cplx_dev(x, win, hop)
+    ms = t(lambda: dsp_amd.stft_cplx_dev(x, win, hop, out=y))
+    es = x.element_size()
+    byts = B * y.shape[1] * (hop + 2 * 257) * es
+    wpad = torch.zeros(512, device='cuda', dtype=dt); wpad[(512 - L) // 2:(512 - L) // 2 + L] = win
+    f = lambda: torch.stft(x, 512, hop_length=hop, window=wpad, center=True, pad_mode='reflect', return_complex=True)
+    try:
+        mt = t(f, 10)
+    except Exception as e:
+        mt = float('nan')
+    print('%s L %d hop %d: %.3f ms  %.1f %% of 8 TB/s (%d B per frame)   torch.stft: %.3f ms' % (str(dt)[6:], L, hop, ms, byts / ms / 8e9 * 100, (hop + 514) * es, mt), flush=True)

@@ -1210,6 +1210,13 @@ int stft_cplx_dev(const char *fn, T *Yd, const T *Xd, const T *wd, size_t B, siz
         HIPCHK(fn, launch_stft_r512_fast_cplx<T>(Yd, Xd, wd, tw, d, scale, s));
         return 0;
     }
+    if constexpr (sizeof(T) == 4) {
+        if ((nfft == 1024 || nfft == 2048) && !tl_force_generic && r512x_cplx_supported(d)) {
+            if (get_twiddles<T>(fn, dev, nfft, 0, tw)) { return 1; }
+            HIPCHK(fn, launch_stft_r512x_cplx(Yd, Xd, wd, tw, d, scale, s));
+            return 0;
+        }
+    }
     if ((pow2 ? nfft : L) * sizeof(T) > LDS_LIMIT) { fprintf(stderr, "error in %s: nfft too large (limit %zu)\n", fn, LDS_LIMIT / sizeof(T)); return 1; }
     if (get_twiddles<T>(fn, dev, nfft, pow2 ? 0 : 1, tw)) { return 1; }
     void *frames = nullptr;

@@ -41,6 +41,7 @@ struct R512XArgs {
     int steps;            // B * sps
     const int *tbl;       // table form: start of frame w at tbl[2 w] (frames need not be equally spaced); else nullptr
     int reach;            // table form: bound on the distance between the starts of the first and last frame of a step
+    float cscale;         // complex form: factor on every output value
 };
 
 constexpr int R512X_TILE = 4 * R512_EXF * 2;          // floats of a wave's exchange tile / row staging
@@ -110,7 +111,10 @@ __device__ __forceinline__ void r512x_swap32(cx<float> &a, cx<float> &b)
     b = cx<float>{__uint_as_float(tx.y), __uint_as_float(ty.y)};
 }
 
-template <int Q, bool FULL, bool MN0, bool EPI, int SPAN, bool ALN>
+// CPLX: the rows are the complex spectra (M + 1 interleaved (re, im) pairs per frame, the imaginary parts of the first and
+// last zero: window_univar followed by fft_fftw_r2hc, reference c/window_univar.c:41-89, c/fft.fftw.r2hc.c:69-78) instead of
+// their powers.
+template <int Q, bool FULL, bool MN0, bool EPI, int SPAN, bool ALN, bool CPLX = false>
 __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *__restrict__ Y, const float *__restrict__ X,
                                                                          const float *__restrict__ win, const float *__restrict__ tw,
                                                                          const R512XArgs a)
@@ -120,7 +124,9 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
     typedef float f2e __attribute__((ext_vector_type(2), aligned(4)));
     constexpr int NFFT = 512 * Q, M = 256 * Q, F = M + 1, FPS = 4 / Q, NWV = R512X_WAVES, NV = SPAN / 256;
     constexpr int WAVE_LDS = R512X_TILE + SPAN;
-    static_assert(FPS * F + 3 <= R512X_TILE, "row staging fits the tile");
+    constexpr int ROWF = CPLX ? 2 * F : F;                 // floats of an output row
+    constexpr int NVI = (FPS * ROWF + 255) / 256;          // whole-vector wave stores of a step's block of rows
+    static_assert(FPS * ROWF + 3 <= R512X_TILE, "row staging fits the tile");
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
     int b = sid / a.sps;
     int w = (sid - b * a.sps) * FPS;
     const float *xb = X + (long long)b * a.ldx;
-    float *yb = Y + (long long)b * a.W * F;
+    float *yb = Y + (long long)b * a.W * ROWF;
 
     const unsigned cnt_addr = ring_lds_addr(ticket);
     unsigned drawn = 0;
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
             const int nb = nsid / a.sps;
             nw = (nsid - nb * a.sps) * FPS;
             nxb = X + (long long)nb * a.ldx;
-            nyb = Y + (long long)nb * a.W * F;
+            nyb = Y + (long long)nb * a.W * ROWF;
         }
     };
 
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
         ring_draw(drawn, cnt_addr);                       // the step after this one: asked for now, needed further down
         // The span of this step was asked for in the middle of the last one; memory operations complete in issue
         // order and behind its NV loads lie that step's 5 row stores, which stay in flight.
-        if (first_step) { ring_wait_vm<0>(); } else { ring_wait_vm<5>(); }
+        if (first_step) { ring_wait_vm<0>(); } else { ring_wait_vm<NVI + 1>(); }
         first_step = false;
         wave_sync();
         R512X_STAMP(0);                                    // wait for the span
@@ -362,57 +368,91 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
         // With A = Z_K + conj Z_(M-K), B = Z_K - conj Z_(M-K), T = -i W_nfft^K B:
         // |X_K|^2 = |A + T|^2 and |X_(M-K)|^2 = |A - T|^2.
         R512X_STAMP(4);                                    // pass-2 reads and transform
-        float pw[16];                                      // pw[k2] = P[K], pw[8 + k2] = P[M - K]
-        float pmid = 4.0f * cx_norm<float>(zz[slot16(8)]); // K = M / 2: lane j == 0 of group 0 only
-        const bool own0 = (r == 0) && (j == 0);
-#pragma unroll
-        for (int k2 = 0; k2 < 8; ++k2) {
-            const C z = zz[slot16(k2)];
-            // (lane 0 of residue 0 is its own partner: the moves hand it its own register 15 - k2, which the last
-            // select replaces by register (16 - k2) % 16)
-            const C own = zz[slot16((16 - k2) & 15)], oth = zz[slot16(15 - k2)];
-            const float mx1 = r512x_mirror(oth.x), my1 = r512x_mirror(oth.y);
-            const float mx2 = r512x_ror1(mx1), my2 = r512x_ror1(my1);
-            C m;
-            if constexpr (Q == 2) {
-                m = C{r == 0 ? mx2 : mx1, r == 0 ? my2 : my1};
-            } else {
-                const float mx3 = r512x_xor32(mx1, lane < 32), my3 = r512x_xor32(my1, lane < 32);
-                m = C{r == 0 ? mx2 : (r == 2 ? mx1 : mx3), r == 0 ? my2 : (r == 2 ? my1 : my3)};
-            }
-            m = C{own0 ? own.x : m.x, own0 ? own.y : m.y};
-            const C A = cx_add_conj<float>(z, m), B = cx_sub_conj<float>(z, m);
-            const C Tw = cx_mul<float>(B, ow[k2]);
-            pw[k2] = cx_norm<float>(A + Tw);
-            pw[8 + k2] = cx_norm<float>(A - Tw);
-        }
-        if (EPI) {
-            power_epilogue_n(pw, a.epi);
-            pmid = power_epilogue(pmid, a.epi);
-        }
         // the step's block of rows in the output, and how it lies against 16-byte boundaries
-        float *yblk = yb + (size_t)w * F;
-        const int nout = __builtin_amdgcn_readfirstlane(min(FPS, a.W - w) * F);
+        float *yblk = yb + (size_t)w * ROWF;
+        const int nout = __builtin_amdgcn_readfirstlane(min(FPS, a.W - w) * ROWF);
         const int head = ring_block_head(yblk);
         const int sh = ring_stage_shift(head);             // value e of the block is staged at xs[sh + e]
-        wave_sync();                                       // every lane has read its tile row: reuse the region
-        R512X_STAMP(5);                                    // split
-        {
-            float *pf = xs + sh + f * F;
+        const bool own0 = (r == 0) && (j == 0);
+        if constexpr (CPLX) {
+            // X_K = A + T, X_(M-K) = conj(A - T), each written to the staging area as soon as it exists; K = M / 2 is
+            // 2 conj Z_(M/2) (lane 0 of residue 0)
+            const float sc = a.cscale;
+            const C zmid = zz[slot16(8)];
+            wave_sync();                                   // every lane has read its tile row (into zz): reuse the region
+            float *pf = xs + sh + f * ROWF;
 #pragma unroll
             for (int k2 = 0; k2 < 8; ++k2) {
+                const C z = zz[slot16(k2)];
+                const C own = zz[slot16((16 - k2) & 15)], oth = zz[slot16(15 - k2)];
+                const float mx1 = r512x_mirror(oth.x), my1 = r512x_mirror(oth.y);
+                const float mx2 = r512x_ror1(mx1), my2 = r512x_ror1(my1);
+                C m;
+                if constexpr (Q == 2) {
+                    m = C{r == 0 ? mx2 : mx1, r == 0 ? my2 : my1};
+                } else {
+                    const float mx3 = r512x_xor32(mx1, lane < 32), my3 = r512x_xor32(my1, lane < 32);
+                    m = C{r == 0 ? mx2 : (r == 2 ? mx1 : mx3), r == 0 ? my2 : (r == 2 ? my1 : my3)};
+                }
+                m = C{own0 ? own.x : m.x, own0 ? own.y : m.y};
+                const C A = cx_add_conj<float>(z, m), B = cx_sub_conj<float>(z, m);
+                const C Tw = cx_mul<float>(B, ow[k2]);
+                const C u = A + Tw, v = A - Tw;
                 const int K = Q * (j + 16 * k2) + r;
-                pf[K] = pw[k2];
-                pf[M - K] = pw[8 + k2];
+                const bool edge = own0 && k2 == 0;         // bins 0 and M: imaginary parts zero
+                pf[2 * K] = sc * u.x; pf[2 * K + 1] = edge ? 0.f : sc * u.y;
+                pf[2 * (M - K)] = sc * v.x; pf[2 * (M - K) + 1] = edge ? 0.f : -sc * v.y;
             }
-            if (own0) { pf[M / 2] = pmid; }
+            if (own0) { pf[M] = 2.0f * sc * zmid.x; pf[M + 1] = -2.0f * sc * zmid.y; }
+            wave_sync();
+            R512X_STAMP(5);
+        } else {
+            float pw[16];                                      // pw[k2] = P[K], pw[8 + k2] = P[M - K]
+            float pmid = 4.0f * cx_norm<float>(zz[slot16(8)]); // K = M / 2: lane j == 0 of group 0 only
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) {
+                const C z = zz[slot16(k2)];
+                // (lane 0 of residue 0 is its own partner: the moves hand it its own register 15 - k2, which the last
+                // select replaces by register (16 - k2) % 16)
+                const C own = zz[slot16((16 - k2) & 15)], oth = zz[slot16(15 - k2)];
+                const float mx1 = r512x_mirror(oth.x), my1 = r512x_mirror(oth.y);
+                const float mx2 = r512x_ror1(mx1), my2 = r512x_ror1(my1);
+                C m;
+                if constexpr (Q == 2) {
+                    m = C{r == 0 ? mx2 : mx1, r == 0 ? my2 : my1};
+                } else {
+                    const float mx3 = r512x_xor32(mx1, lane < 32), my3 = r512x_xor32(my1, lane < 32);
+                    m = C{r == 0 ? mx2 : (r == 2 ? mx1 : mx3), r == 0 ? my2 : (r == 2 ? my1 : my3)};
+                }
+                m = C{own0 ? own.x : m.x, own0 ? own.y : m.y};
+                const C A = cx_add_conj<float>(z, m), B = cx_sub_conj<float>(z, m);
+                const C Tw = cx_mul<float>(B, ow[k2]);
+                pw[k2] = cx_norm<float>(A + Tw);
+                pw[8 + k2] = cx_norm<float>(A - Tw);
+            }
+            if (EPI) {
+                power_epilogue_n(pw, a.epi);
+                pmid = power_epilogue(pmid, a.epi);
+            }
+            wave_sync();                                       // every lane has read its tile row: reuse the region
+            R512X_STAMP(5);                                    // split
+            {
+                float *pf = xs + sh + f * F;
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) {
+                    const int K = Q * (j + 16 * k2) + r;
+                    pf[K] = pw[k2];
+                    pf[M - K] = pw[8 + k2];
+                }
+                if (own0) { pf[M / 2] = pmid; }
+            }
+            wave_sync();
         }
-        wave_sync();
 
         // ---- five stores: four of whole 16-byte vectors, one for the values before and after them.  Surplus
         // lanes repeat a valid store (same value to the same address).
         R512X_STAMP(6);                                    // staging
-        ring_store_rows<4, R512X_NOSTORE != 0>(yblk, xs + sh, head, nout, lane);
+        ring_store_rows<NVI, R512X_NOSTORE != 0>(yblk, xs + sh, head, nout, lane);
         R512X_STAMP(7);                                    // stores issued
         if (!more) { break; }
         wave_sync();                                       // staging reads are done before the next step writes the tile
@@ -449,16 +489,16 @@ bool r512x_supported(const FrameDesc &d)
            d.ss0 > -(1ll << 30) && d.ss0 < (1ll << 30) && d.rd_shift >= 0 && d.rd_shift < (1ll << 30);
 }
 
-template <int Q, bool FULL, bool MN0, bool EPI, int SPAN, bool ALN>
+template <int Q, bool FULL, bool MN0, bool EPI, int SPAN, bool ALN, bool CPLX = false>
 static hipError_t launch_r512x_inst(float *Y, const float *X, const float *win, const float *tw, const R512XArgs &a, hipStream_t s)
 {
     const size_t lds = ((size_t)R512X_WAVES * (R512X_TILE + SPAN) + (R512X_TWD_LDS ? 512 : 0) + 256) * sizeof(float) + 16;
     static LdsGrant grant;
-    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r512x_kernel<Q, FULL, MN0, EPI, SPAN, ALN>), lds, grant); e != hipSuccess) { return e; }
+    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r512x_kernel<Q, FULL, MN0, EPI, SPAN, ALN, CPLX>), lds, grant); e != hipSuccess) { return e; }
     long long grid = ((long long)a.steps + R512X_WAVES - 1) / R512X_WAVES;
     if (grid > 256) { grid = 256; }                     // one 8-wave workgroup per CU
     grid = (grid + 7) & ~7ll;                           // whole groups of 8 workgroups (one per XCD)
-    hipLaunchKernelGGL((stft_r512x_kernel<Q, FULL, MN0, EPI, SPAN, ALN>), dim3((unsigned)grid), dim3(64 * R512X_WAVES), lds, s, Y, X, win, tw, a);
+    hipLaunchKernelGGL((stft_r512x_kernel<Q, FULL, MN0, EPI, SPAN, ALN, CPLX>), dim3((unsigned)grid), dim3(64 * R512X_WAVES), lds, s, Y, X, win, tw, a);
     return hipGetLastError();
 }
 
@@ -495,6 +535,39 @@ hipError_t launch_stft_r512x(float *Y, const float *X, const float *win, const f
     if (d.tbl || (d.stp & 1)) { return launch_r512x_shape<2, 2048, false>(Y, X, win, tw, a, d, s); }
     if (d.stp + 1024 <= 1280) { return launch_r512x_shape<2, 1280, true>(Y, X, win, tw, a, d, s); }
     return launch_r512x_shape<2, 2048, true>(Y, X, win, tw, a, d, s);
+}
+
+// The complex form: Y[b][w][nfft/2+1] interleaved (re, im) pairs times `scale`; equally spaced frames, no mean removal.
+bool r512x_cplx_supported(const FrameDesc &d)
+{
+    return r512x_supported(d) && d.tbl == nullptr && !d.mn0 && !d.epi.any() && (long long)d.W * (d.nfft + 2) < (1ll << 30);
+}
+
+template <int Q, int SPAN, bool ALN>
+static hipError_t launch_r512x_cplx_shape(float *Y, const float *X, const float *win, const float *tw, const R512XArgs &a, const FrameDesc &d, hipStream_t s)
+{
+#if R512X_MINIMAL
+    return hipErrorInvalidValue;
+#else
+    if (d.L == d.nfft) { return launch_r512x_inst<Q, true, false, false, SPAN, ALN, true>(Y, X, win, tw, a, s); }
+    return launch_r512x_inst<Q, false, false, false, SPAN, ALN, true>(Y, X, win, tw, a, s);
+#endif
+}
+
+hipError_t launch_stft_r512x_cplx(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, double scale, hipStream_t s)
+{
+    const int Q = d.nfft / 512, fps = 4 / Q;
+    R512XArgs a{};
+    a.ldx = d.ldx; a.N = (int)d.N; a.L = d.L; a.W = d.W; a.stp = d.stp; a.ss0 = (int)d.ss0;
+    a.rd_shift = (int)d.rd_shift; a.edge = d.edge; a.epi = d.epi;
+    a.sps = (d.W + fps - 1) / fps;
+    a.steps = d.B * a.sps;
+    a.tbl = nullptr; a.reach = 0;
+    a.cscale = (float)scale;
+    if (Q == 4) { return launch_r512x_cplx_shape<4, 2048, true>(Y, X, win, tw, a, d, s); }
+    if (d.stp & 1) { return launch_r512x_cplx_shape<2, 2048, false>(Y, X, win, tw, a, d, s); }
+    if (d.stp + 1024 <= 1280) { return launch_r512x_cplx_shape<2, 1280, true>(Y, X, win, tw, a, d, s); }
+    return launch_r512x_cplx_shape<2, 2048, true>(Y, X, win, tw, a, d, s);
 }
 
 }  // namespace dsp

@@ -24,3 +24,11 @@ for (dt, B, N, L, hop) in ((torch.float32, 1024, 160000, 400, 160), (torch.float
     except Exception as e:
         mt = float('nan')
     print('%s L %d hop %d: %.3f ms  %.1f %% of 8 TB/s (%d B per frame)   torch.stft: %.3f ms' % (str(dt)[6:], L, hop, ms, byts / ms / 8e9 * 100, (hop + 514) * es, mt), flush=True)
+for (nfft, hop) in ((1024, 256), (2048, 512)):
+    x = torch.randn((64, 2646000), device='cuda') * 0.1
+    win = torch.from_numpy(dsp_amd.hann(nfft)).cuda()
+    y = dsp_amd.stft_cplx_dev(x, win, hop, nfft=nfft)
+    ms = t(lambda: dsp_amd.stft_cplx_dev(x, win, hop, nfft=nfft, out=y), 20)
+    byts = 64 * y.shape[1] * (hop + nfft + 2) * 4
+    mt = t(lambda: torch.stft(x, nfft, hop_length=hop, window=win, center=True, pad_mode='reflect', return_complex=True), 6)
+    print('float32 nfft %d hop %d: %.3f ms  %.1f %% of 8 TB/s   torch.stft: %.3f ms' % (nfft, hop, ms, byts / ms / 8e9 * 100, mt), flush=True)

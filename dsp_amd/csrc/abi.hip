@@ -1216,6 +1216,11 @@ int stft_cplx_dev(const char *fn, T *Yd, const T *Xd, const T *wd, size_t B, siz
             HIPCHK(fn, launch_stft_r512x_cplx(Yd, Xd, wd, tw, d, scale, s));
             return 0;
         }
+        if (nfft == 256 && !tl_force_generic && r256_cplx_supported(d)) {
+            if (get_twiddles<T>(fn, dev, nfft, 0, tw)) { return 1; }
+            HIPCHK(fn, launch_stft_r256_cplx(Yd, Xd, wd, tw, d, scale, s));
+            return 0;
+        }
     }
     if ((pow2 ? nfft : L) * sizeof(T) > LDS_LIMIT) { fprintf(stderr, "error in %s: nfft too large (limit %zu)\n", fn, LDS_LIMIT / sizeof(T)); return 1; }
     if (get_twiddles<T>(fn, dev, nfft, pow2 ? 0 : 1, tw)) { return 1; }

@@ -33,6 +33,7 @@ struct R256Args {
     int steps;            // B * sps
     const int *tbl;       // table form: start of frame w at tbl[2 w] (frames need not be equally spaced); else nullptr
     int reach;            // table form: bound on the distance between the starts of the first and last frame of a step
+    float cscale;         // complex form: factor on every output value
 };
 
 constexpr int R256_FP = 152;                         // complex slots per frame in the exchange tile (16 rows, pitch 9, + 8)
@@ -70,7 +71,10 @@ __device__ __forceinline__ void dft8c(cx<float> (&a)[8])
     }
 }
 
-template <int NR, bool MN0, bool EPI, int SPAN, bool ALN>
+// CPLX: the rows are the complex spectra (129 interleaved (re, im) pairs per frame, the imaginary parts of the first and
+// last zero: window_univar followed by fft_fftw_r2hc, reference c/window_univar.c:41-89, c/fft.fftw.r2hc.c:69-78) instead of
+// their powers.
+template <int NR, bool MN0, bool EPI, int SPAN, bool ALN, bool CPLX = false>
 __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__restrict__ Y, const float *__restrict__ X,
                                                                        const float *__restrict__ win, const float *__restrict__ tw,
                                                                        const R256Args a)
@@ -79,7 +83,9 @@ __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__
     typedef float f2e __attribute__((ext_vector_type(2), aligned(4)));
     constexpr int M = 128, F = 129, FPS = 8, NWV = R256_WAVES, NV = SPAN / 256;
     constexpr int WAVE_LDS = R256_TILE + SPAN;
-    static_assert(FPS * F + 3 <= R256_TILE, "row staging fits the tile");
+    constexpr int ROWF = CPLX ? 2 * F : F;                 // floats of an output row
+    constexpr int NVI = (FPS * ROWF + 255) / 256;          // whole-vector wave stores of a step's block of rows
+    static_assert(FPS * ROWF + 3 <= R256_TILE, "row staging fits the tile");
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__
     int b = sid / a.sps;
     int w = (sid - b * a.sps) * FPS;
     const float *xb = X + (long long)b * a.ldx;
-    float *yb = Y + (long long)b * a.W * F;
+    float *yb = Y + (long long)b * a.W * ROWF;
 
     const unsigned cnt_addr = ring_lds_addr(ticket);
     unsigned drawn = 0;
@@ -175,7 +181,7 @@ __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__
             const int nb = nsid / a.sps;
             nw = (nsid - nb * a.sps) * FPS;
             nxb = X + (long long)nb * a.ldx;
-            nyb = Y + (long long)nb * a.W * F;
+            nyb = Y + (long long)nb * a.W * ROWF;
         }
     };
 
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__
         ring_draw(drawn, cnt_addr);                        // the step after this one: asked for now, needed further down
         // The span of this step was asked for in the middle of the last one; memory operations complete in issue
         // order and behind its NV loads lie that step's 6 row stores, which stay in flight.
-        if (first_step) { ring_wait_vm<0>(); } else { ring_wait_vm<6>(); }
+        if (first_step) { ring_wait_vm<0>(); } else { ring_wait_vm<NVI + 1>(); }
         first_step = false;
         wave_sync();
 
@@ -261,58 +267,96 @@ __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__
         // partner of K = j + 8 + 16 k2: Z[128 - K] = row a, register 7 - k2, of lane 8 - j   (j = 0: own zb[7 - k2]).
         // With A = Z_K + conj Z_(128-K), B = Z_K - conj Z_(128-K), T = -i W256^K B:
         // |X_K|^2 = |A + T|^2 and |X_(128-K)|^2 = |A - T|^2.  K < 64 (k2 < 4) covers every pair once; K = 64 pairs with itself.
-        float pw[16];                                      // [k2]: P[Ka], [4 + k2]: P[128 - Ka], [8 + k2]: P[Kb], [12 + k2]: P[128 - Kb]
-        float pmid = 4.0f * cx_norm<float>(za[slot8(4)]);  // K = 64: lane j == 0 only
-#pragma unroll
-        for (int k2 = 0; k2 < 4; ++k2) {
-            auto partner = [&](const C oth, const C own) {
-                const float px = r256_shr1(r256_half_mirror(oth.x)), py = r256_shr1(r256_half_mirror(oth.y));
-                return C{(j == 0) ? own.x : px, (j == 0) ? own.y : py};
-            };
-            {
-                const C z = za[slot8(k2)];
-                const C m = partner(zb[slot8(7 - k2)], za[slot8((8 - k2) & 7)]);
-                const C A = cx_add_conj<float>(z, m), B = cx_sub_conj<float>(z, m);
-                const C Tw = cx_mul<float>(B, owa[k2]);
-                pw[k2] = cx_norm<float>(A + Tw);
-                pw[4 + k2] = cx_norm<float>(A - Tw);
-            }
-            {
-                const C z = zb[slot8(k2)];
-                const C m = partner(za[slot8(7 - k2)], zb[slot8(7 - k2)]);
-                const C A = cx_add_conj<float>(z, m), B = cx_sub_conj<float>(z, m);
-                const C Tw = cx_mul<float>(B, owb[k2]);
-                pw[8 + k2] = cx_norm<float>(A + Tw);
-                pw[12 + k2] = cx_norm<float>(A - Tw);
-            }
-        }
-        if (EPI) {
-            power_epilogue_n(pw, a.epi);
-            pmid = power_epilogue(pmid, a.epi);
-        }
         // the step's block of rows in the output, and how it lies against 16-byte boundaries
-        float *yblk = yb + (size_t)w * F;
-        const int nout = __builtin_amdgcn_readfirstlane(min(FPS, a.W - w) * F);
+        float *yblk = yb + (size_t)w * ROWF;
+        const int nout = __builtin_amdgcn_readfirstlane(min(FPS, a.W - w) * ROWF);
         const int head = ring_block_head(yblk);
         const int sh = ring_stage_shift(head);             // value e of the block is staged at xs[sh + e]
-        wave_sync();                                       // every lane has read its tile rows: reuse the region
-        {
-            float *pf = xs + sh + f * F;
+        if constexpr (CPLX) {
+            // X_K = A + T, X_(128-K) = conj(A - T), each written to the staging area as soon as it exists; K = 64 is
+            // 2 conj Z_64 (lane j == 0)
+            const float sc = a.cscale;
+            const C zmid = za[slot8(4)];
+            wave_sync();                                   // every lane has read its tile rows (into za, zb): reuse the region
+            float *pf = xs + sh + f * ROWF;
 #pragma unroll
             for (int k2 = 0; k2 < 4; ++k2) {
+                auto partner = [&](const C oth, const C own) {
+                    const float px = r256_shr1(r256_half_mirror(oth.x)), py = r256_shr1(r256_half_mirror(oth.y));
+                    return C{(j == 0) ? own.x : px, (j == 0) ? own.y : py};
+                };
                 const int Ka = j + 16 * k2, Kb = Ka + 8;
-                pf[Ka] = pw[k2];
-                pf[M - Ka] = pw[4 + k2];
-                pf[Kb] = pw[8 + k2];
-                pf[M - Kb] = pw[12 + k2];
+                {
+                    const C z = za[slot8(k2)];
+                    const C m = partner(zb[slot8(7 - k2)], za[slot8((8 - k2) & 7)]);
+                    const C A = cx_add_conj<float>(z, m), B = cx_sub_conj<float>(z, m);
+                    const C Tw = cx_mul<float>(B, owa[k2]);
+                    const C u = A + Tw, v = A - Tw;
+                    const bool edge = (j == 0) && k2 == 0;     // bins 0 and 128: imaginary parts zero
+                    pf[2 * Ka] = sc * u.x; pf[2 * Ka + 1] = edge ? 0.f : sc * u.y;
+                    pf[2 * (M - Ka)] = sc * v.x; pf[2 * (M - Ka) + 1] = edge ? 0.f : -sc * v.y;
+                }
+                {
+                    const C z = zb[slot8(k2)];
+                    const C m = partner(za[slot8(7 - k2)], zb[slot8(7 - k2)]);
+                    const C A = cx_add_conj<float>(z, m), B = cx_sub_conj<float>(z, m);
+                    const C Tw = cx_mul<float>(B, owb[k2]);
+                    const C u = A + Tw, v = A - Tw;
+                    pf[2 * Kb] = sc * u.x; pf[2 * Kb + 1] = sc * u.y;
+                    pf[2 * (M - Kb)] = sc * v.x; pf[2 * (M - Kb) + 1] = -sc * v.y;
+                }
             }
-            if (j == 0) { pf[M / 2] = pmid; }
+            if (j == 0) { pf[M] = 2.0f * sc * zmid.x; pf[M + 1] = -2.0f * sc * zmid.y; }
+            wave_sync();
+        } else {
+            float pw[16];                                      // [k2]: P[Ka], [4 + k2]: P[128 - Ka], [8 + k2]: P[Kb], [12 + k2]: P[128 - Kb]
+            float pmid = 4.0f * cx_norm<float>(za[slot8(4)]);  // K = 64: lane j == 0 only
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) {
+                auto partner = [&](const C oth, const C own) {
+                    const float px = r256_shr1(r256_half_mirror(oth.x)), py = r256_shr1(r256_half_mirror(oth.y));
+                    return C{(j == 0) ? own.x : px, (j == 0) ? own.y : py};
+                };
+                {
+                    const C z = za[slot8(k2)];
+                    const C m = partner(zb[slot8(7 - k2)], za[slot8((8 - k2) & 7)]);
+                    const C A = cx_add_conj<float>(z, m), B = cx_sub_conj<float>(z, m);
+                    const C Tw = cx_mul<float>(B, owa[k2]);
+                    pw[k2] = cx_norm<float>(A + Tw);
+                    pw[4 + k2] = cx_norm<float>(A - Tw);
+                }
+                {
+                    const C z = zb[slot8(k2)];
+                    const C m = partner(za[slot8(7 - k2)], zb[slot8(7 - k2)]);
+                    const C A = cx_add_conj<float>(z, m), B = cx_sub_conj<float>(z, m);
+                    const C Tw = cx_mul<float>(B, owb[k2]);
+                    pw[8 + k2] = cx_norm<float>(A + Tw);
+                    pw[12 + k2] = cx_norm<float>(A - Tw);
+                }
+            }
+            if (EPI) {
+                power_epilogue_n(pw, a.epi);
+                pmid = power_epilogue(pmid, a.epi);
+            }
+            wave_sync();                                       // every lane has read its tile rows: reuse the region
+            {
+                float *pf = xs + sh + f * F;
+#pragma unroll
+                for (int k2 = 0; k2 < 4; ++k2) {
+                    const int Ka = j + 16 * k2, Kb = Ka + 8;
+                    pf[Ka] = pw[k2];
+                    pf[M - Ka] = pw[4 + k2];
+                    pf[Kb] = pw[8 + k2];
+                    pf[M - Kb] = pw[12 + k2];
+                }
+                if (j == 0) { pf[M / 2] = pmid; }
+            }
+            wave_sync();
         }
-        wave_sync();
 
         // ---- six stores: five of whole 16-byte vectors, one for the values before and after them.  Surplus
         // lanes repeat a valid store (same value to the same address).
-        ring_store_rows<5>(yblk, xs + sh, head, nout, lane);
+        ring_store_rows<NVI>(yblk, xs + sh, head, nout, lane);
         if (!more) { break; }
         wave_sync();                                       // staging reads are done before the next step writes the tile
         sid = nsid; w = nw; xb = nxb; yb = nyb;
@@ -333,16 +377,16 @@ bool r256_supported(const FrameDesc &d)
            d.ss0 > -(1ll << 30) && d.ss0 < (1ll << 30) && d.rd_shift >= 0 && d.rd_shift < (1ll << 30);
 }
 
-template <int NR, bool MN0, bool EPI, int SPAN, bool ALN>
+template <int NR, bool MN0, bool EPI, int SPAN, bool ALN, bool CPLX = false>
 static hipError_t launch_r256_inst(float *Y, const float *X, const float *win, const float *tw, const R256Args &a, hipStream_t s)
 {
     const size_t lds = ((size_t)R256_WAVES * (R256_TILE + SPAN) + 256) * sizeof(float) + 16;
     static LdsGrant grant;
-    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r256_kernel<NR, MN0, EPI, SPAN, ALN>), lds, grant); e != hipSuccess) { return e; }
+    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r256_kernel<NR, MN0, EPI, SPAN, ALN, CPLX>), lds, grant); e != hipSuccess) { return e; }
     long long grid = ((long long)a.steps + R256_WAVES - 1) / R256_WAVES;
     if (grid > 256) { grid = 256; }                     // one 8-wave workgroup per CU
     grid = (grid + 7) & ~7ll;                           // whole groups of 8 workgroups (one per XCD)
-    hipLaunchKernelGGL((stft_r256_kernel<NR, MN0, EPI, SPAN, ALN>), dim3((unsigned)grid), dim3(64 * R256_WAVES), lds, s, Y, X, win, tw, a);
+    hipLaunchKernelGGL((stft_r256_kernel<NR, MN0, EPI, SPAN, ALN, CPLX>), dim3((unsigned)grid), dim3(64 * R256_WAVES), lds, s, Y, X, win, tw, a);
     return hipGetLastError();
 }
 
@@ -378,6 +422,32 @@ hipError_t launch_stft_r256(float *Y, const float *X, const float *win, const fl
     if (reach <= 1024) { return nr13 ? launch_r256_shape<13, 1024, true>(Y, X, win, tw, a, d, s) : launch_r256_shape<16, 1024, true>(Y, X, win, tw, a, d, s); }
     if (reach <= 1280) { return launch_r256_shape<16, 1280, true>(Y, X, win, tw, a, d, s); }
     return launch_r256_shape<16, 2048, true>(Y, X, win, tw, a, d, s);
+}
+
+// The complex form: Y[b][w][129] interleaved (re, im) pairs times `scale`; equally spaced frames, no mean removal.
+bool r256_cplx_supported(const FrameDesc &d)
+{
+    return r256_supported(d) && d.tbl == nullptr && !d.mn0 && !d.epi.any() && (long long)d.W * 258 < (1ll << 30);
+}
+
+hipError_t launch_stft_r256_cplx(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, double scale, hipStream_t s)
+{
+    R256Args a{};
+    a.ldx = d.ldx; a.N = (int)d.N; a.L = d.L; a.W = d.W; a.stp = d.stp; a.ss0 = (int)d.ss0;
+    a.rd_shift = (int)d.rd_shift; a.edge = d.edge; a.epi = d.epi;
+    a.sps = (d.W + 7) / 8;
+    a.steps = d.B * a.sps;
+    a.tbl = nullptr; a.reach = 0;
+    a.cscale = (float)scale;
+    const int reach = 7 * d.stp + 256;
+    const bool nr13 = d.L > 192 && d.L <= 208;
+    if (d.stp & 1) { return launch_r256_inst<16, false, false, 2048, false, true>(Y, X, win, tw, a, s); }
+    if (reach <= 1024) {
+        return nr13 ? launch_r256_inst<13, false, false, 1024, true, true>(Y, X, win, tw, a, s)
+                    : launch_r256_inst<16, false, false, 1024, true, true>(Y, X, win, tw, a, s);
+    }
+    if (reach <= 1280) { return launch_r256_inst<16, false, false, 1280, true, true>(Y, X, win, tw, a, s); }
+    return launch_r256_inst<16, false, false, 2048, true, true>(Y, X, win, tw, a, s);
 }
 
 }  // namespace dsp

@@ -1338,7 +1338,9 @@ def test_complex_spectrogram(O, D, dt):
              (2, 6000, 256, 64, 256, False), (1, 9000, 1024, 256, 1024, False), (1, 9000, 400, 600, 512, False), (2, 3000, 100, 50, 120, False),
              # the 1024 / 2048-point kernel's complex form (float32; float64 takes the unfused kernels)
              (2, 20000, 800, 200, 1024, False), (3, 9000, 1024, 512, 1024, True), (2, 30000, 2048, 512, 2048, False), (2, 12001, 1200, 301, 2048, False),
-             (1, 9001, 1024, 255, 1024, False), (5, 4099, 2048, 1024, 2048, False)]
+             (1, 9001, 1024, 255, 1024, False), (5, 4099, 2048, 1024, 2048, False),
+             # the 256-point kernel's (float32)
+             (3, 8000, 200, 80, 256, False), (2, 8001, 256, 81, 256, True), (4, 3001, 256, 128, 256, False), (1, 9000, 130, 200, 256, False)]
     for (B, N, L, hop, nfft, snip) in cases:
         x = (rng.standard_normal((B, N)) * 0.1).astype(dt)
         win = D.povey(L, dt) if L > 1 else np.ones(1, dt)

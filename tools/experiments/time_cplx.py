@@ -32,3 +32,8 @@ for (nfft, hop) in ((1024, 256), (2048, 512)):
     byts = 64 * y.shape[1] * (hop + nfft + 2) * 4
     mt = t(lambda: torch.stft(x, nfft, hop_length=hop, window=win, center=True, pad_mode='reflect', return_complex=True), 6)
     print('float32 nfft %d hop %d: %.3f ms  %.1f %% of 8 TB/s   torch.stft: %.3f ms' % (nfft, hop, ms, byts / ms / 8e9 * 100, mt), flush=True)
+x = torch.randn((1024, 80000), device='cuda') * 0.1
+win = torch.from_numpy(dsp_amd.hann(200)).cuda()
+y = dsp_amd.stft_cplx_dev(x, win, 80, nfft=256)
+ms = t(lambda: dsp_amd.stft_cplx_dev(x, win, 80, nfft=256, out=y))
+print('float32 nfft 256 L 200 hop 80: %.3f ms  %.1f %% of 8 TB/s' % (ms, 1024 * y.shape[1] * (80 + 258) * 4 / ms / 8e9 * 100), flush=True)

@@ -44,6 +44,7 @@ struct R4096Args {
     int frames;           // B * W
     int B;                // signals
     unsigned *take;       // run form: 8 counters (one per blockIdx % 8), zero at launch
+    float cscale;         // complex form: factor on every output value
 };
 
 // Counters of the run form: R4096_SLOTS sets of 8, used in turn by successive launches on a device (how a
@@ -148,7 +149,12 @@ __device__ __forceinline__ int zpos(int k) { return k ^ (((k >> 5) & 1) << 3); }
 
 template <int R> using rot = std::integral_constant<int, R>;
 
-template <bool FULL, bool MN0, bool EPI, bool RUN>
+// CPLX: the rows are the complex spectra (2049 interleaved (re, im) pairs per frame, the imaginary parts of the first and
+// last zero: window_univar followed by fft_fftw_r2hc, reference c/window_univar.c:41-89, c/fft.fftw.r2hc.c:69-78) instead of
+// their powers.  In the run form the frame in the registers is the true one rotated by ROT quarters of its length, which
+// multiplies bin k by (-i)^(ROT k): the complex form multiplies back by i^(ROT k) -- a swap and a sign, chosen at compile
+// time, since a lane's bins are 4 lane + c + 256 m and 2048 minus those.
+template <bool FULL, bool MN0, bool EPI, bool RUN, bool CPLX = false>
 __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *__restrict__ Y, const float *__restrict__ X,
                                                                          const float *__restrict__ win, const float *__restrict__ tw,
                                                                          const R4096Args a)
@@ -544,7 +550,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         R4096_STAMP(4);
 
         // ---------------- split + power + store: lane handles bins k = 4 lane + c + 256 m and 2048 - k ----------------
-        float *y = Y + (RUN ? (long long)run_b * a.W + run_w0 + tpos : cur.row) * ((R4096_HACK & 4) ? 2048 : F);
+        float *y = Y + (RUN ? (long long)run_b * a.W + run_w0 + tpos : cur.row) * ((R4096_HACK & 4) ? 2048 : (CPLX ? 2 * F : F));
         const C2 *zk = ex + zpos(4 * lane);                                // Z[k] at zk[256 m + c]
         const C2 *zq0 = ex + zpos(M - 4 * lane) - 768;                     // Z[2048 - 4 lane - 256 m] at zq0[256 (3 - m)]
         const C2 *zq4 = ex + zpos(M - 4 - 4 * lane) - 768;                 // Z[2048 - 4 lane - 256 m - 4 + i] at zq4[256 (3 - m) + i]
@@ -554,6 +560,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             float p[4], q[4];
+            C2 xu[4], xv[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const C2 z = zk[256 * m + c];
@@ -566,10 +573,33 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
                 if (m > 0) { B = cx_mul<float>(B, W64C[8 * m], W64C[8 * m + 1]); }
 #endif
                 const C2 Tw = cx_mul<float>(B, ow4[c]);
-                p[c] = cx_norm<float>(A + Tw); q[c] = cx_norm<float>(A - Tw);
+                if constexpr (CPLX) {
+                    // X_k = A + T, X_(2048-k) = conj(A - T); times i^(ROT c) and i^(-ROT c): the rotation of the run form undone
+                    constexpr int RC = RUN ? ROT : 0;
+                    const float sc = a.cscale;
+                    C2 u = (A + Tw) * C2{sc, sc}, v = (A - Tw) * C2{sc, -sc};
+                    const int pu = (RC * c) & 3, pv = (4 - ((RC * c) & 3)) & 3;
+                    auto times_i_pow = [](const C2 w, const int e) {           // w * i^e
+                        return e == 0 ? w : e == 1 ? C2{-w.y, w.x} : e == 2 ? C2{-w.x, -w.y} : C2{w.y, -w.x};
+                    };
+                    u = times_i_pow(u, pu); v = times_i_pow(v, pv);
+                    if (m == 0 && c == 0) { u.y = (lane == 0) ? 0.f : u.y; v.y = (lane == 0) ? 0.f : v.y; }   // bins 0 and 2048
+                    xu[c] = u; xv[c] = v;
+                } else {
+                    p[c] = cx_norm<float>(A + Tw); q[c] = cx_norm<float>(A - Tw);
+                }
             }
             if (EPI) { power_epilogue_n(p, a.epi); power_epilogue_n(q, a.epi); }
             const int k0 = 4 * lane + 256 * m;
+            if constexpr (CPLX) {
+                // bins k0 .. k0 + 3 and 2045 - k0 .. 2048 - k0: 32 bytes each way
+                float *yf = y + 2 * k0, *yr = y + 2 * (M - 3 - k0);
+                *reinterpret_cast<float4_u *>(yf) = float4_u{xu[0].x, xu[0].y, xu[1].x, xu[1].y};
+                *reinterpret_cast<float4_u *>(yf + 4) = float4_u{xu[2].x, xu[2].y, xu[3].x, xu[3].y};
+                *reinterpret_cast<float4_u *>(yr) = float4_u{xv[3].x, xv[3].y, xv[2].x, xv[2].y};
+                *reinterpret_cast<float4_u *>(yr + 4) = float4_u{xv[1].x, xv[1].y, xv[0].x, xv[0].y};
+                continue;
+            }
 #if R4096_ABLATE & 1
             asm volatile("" :: "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]));
             if (a.N == -12345)
@@ -589,13 +619,19 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
             // same address: a store under `if (lane == 0)` sits behind a branch, the count of stores after
             // the prefetch loads is then unknown at compile time, and the wait for the loads also waits
             // for the first store of this row to complete.
+            if constexpr (CPLX) {
+                // bin 1024 is 2 conj Z_1024 (times i^(ROT 1024) = 1); stored by every lane, as the power form's is
+                const C2 zmid = ex[1024];
+                typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+                *reinterpret_cast<f2u *>(y + 2048) = f2u{2.0f * a.cscale * zmid.x, -2.0f * a.cscale * zmid.y};
+            }
             float p = 4.0f * cx_norm<float>(ex[1024]);
             if (EPI) { p = power_epilogue(p, a.epi); }
 #if R4096_ABLATE & 1
             asm volatile("" :: "v"(p));
             if (a.N == -12345)
 #endif
-            y[1024] = p;
+            if constexpr (!CPLX) { y[1024] = p; }
         }
         R4096_STAMP(5);
         R4096_PRIO(2, 0);
@@ -686,12 +722,12 @@ hipEvent_t g_take_ev[64][R4096_SLOTS];
 bool g_take_busy[64][R4096_SLOTS];
 }  // namespace
 
-template <bool FULL, bool MN0, bool EPI, bool RUN>
+template <bool FULL, bool MN0, bool EPI, bool RUN, bool CPLX = false>
 static hipError_t launch_r4096_inst(float *Y, const float *X, const float *win, const float *tw, const R4096Args &a, hipStream_t s, unsigned *take)
 {
     const size_t lds = 4096 * sizeof(float) + (size_t)R4096_WAVES * R4096_WAVE_C * sizeof(float2) + (RUN ? (256 + 64 * 8) * sizeof(float2) : 0);
     static LdsGrant grant;
-    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r4096_kernel<FULL, MN0, EPI, RUN>), lds, grant); e != hipSuccess) { return e; }
+    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r4096_kernel<FULL, MN0, EPI, RUN, CPLX>), lds, grant); e != hipSuccess) { return e; }
     long long grid = ((long long)a.frames + R4096_WAVES - 1) / R4096_WAVES;
     if (grid > 256) { grid = 256; }                      // one 8-wave workgroup per CU (151 KB of LDS each)
     grid = (grid + 7) & ~7ll;
@@ -700,7 +736,7 @@ static hipError_t launch_r4096_inst(float *Y, const float *X, const float *win, 
         // the caller's counters (it answers for launches that overlap)
         b.take = take;
         if (hipError_t e = hipMemsetAsync(b.take, 0, 8 * sizeof(unsigned), s); e != hipSuccess) { return e; }
-        hipLaunchKernelGGL((stft_r4096_kernel<FULL, MN0, EPI, RUN>), dim3((unsigned)grid), dim3(64 * R4096_WAVES), lds, s, Y, X, win, tw, b);
+        hipLaunchKernelGGL((stft_r4096_kernel<FULL, MN0, EPI, RUN, CPLX>), dim3((unsigned)grid), dim3(64 * R4096_WAVES), lds, s, Y, X, win, tw, b);
         return hipGetLastError();
     }
     if (RUN) {
@@ -720,12 +756,12 @@ static hipError_t launch_r4096_inst(float *Y, const float *X, const float *win, 
         }
         b.take = g_take_base[dev] + 8 * slot;
         if (hipError_t e = hipMemsetAsync(b.take, 0, 8 * sizeof(unsigned), s); e != hipSuccess) { return e; }
-        hipLaunchKernelGGL((stft_r4096_kernel<FULL, MN0, EPI, RUN>), dim3((unsigned)grid), dim3(64 * R4096_WAVES), lds, s, Y, X, win, tw, b);
+        hipLaunchKernelGGL((stft_r4096_kernel<FULL, MN0, EPI, RUN, CPLX>), dim3((unsigned)grid), dim3(64 * R4096_WAVES), lds, s, Y, X, win, tw, b);
         if (hipError_t e = hipGetLastError(); e != hipSuccess) { return e; }
         g_take_busy[dev][slot] = true;
         return hipEventRecord(ev, s);
     }
-    hipLaunchKernelGGL((stft_r4096_kernel<FULL, MN0, EPI, RUN>), dim3((unsigned)grid), dim3(64 * R4096_WAVES), lds, s, Y, X, win, tw, b);
+    hipLaunchKernelGGL((stft_r4096_kernel<FULL, MN0, EPI, RUN, CPLX>), dim3((unsigned)grid), dim3(64 * R4096_WAVES), lds, s, Y, X, win, tw, b);
     return hipGetLastError();
 }
 
@@ -755,6 +791,29 @@ hipError_t launch_stft_r4096(float *Y, const float *X, const float *win, const f
     if (d.mn0) { return epi ? DSP_R4096(false, true, true, false) : DSP_R4096(false, true, false, false); }
     return epi ? DSP_R4096(false, false, true, false) : DSP_R4096(false, false, false, false);
 #undef DSP_R4096
+}
+
+// The complex form: Y[b][w][2049] interleaved (re, im) pairs times `scale`; equally spaced frames, no mean removal.
+bool r4096_cplx_supported(const FrameDesc &d)
+{
+    return r4096_supported(d) && d.tbl == nullptr && !d.mn0 && !d.epi.any() && (long long)d.B * d.W < (1ll << 30);
+}
+
+hipError_t launch_stft_r4096_cplx(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, double scale, hipStream_t s)
+{
+    R4096Args a{};
+    a.ldx = d.ldx; a.N = d.N; a.ss0 = d.ss0; a.rd_shift = d.rd_shift; a.tbl = nullptr;
+    a.L = d.L; a.W = d.W; a.stp = d.stp; a.edge = d.edge; a.epi = d.epi;
+    a.frames = d.B * d.W;
+    a.B = d.B;
+    a.cscale = (float)scale;
+    const bool full = d.L == 4096;
+    long long min_runs = 2 * 256 * R4096_WAVES;
+    if (const char *e = getenv("DSP_R4096_MIN_RUNS")) { min_runs = atoll(e) > 0 ? atoll(e) : (1ll << 62); }
+    const long long runs = (long long)d.B * ((d.W + R4096_RUN - 1) / R4096_RUN);
+    if (full && d.stp == 1024 && runs >= min_runs) { return launch_r4096_inst<true, false, false, true, true>(Y, X, win, tw, a, s, nullptr); }
+    if (full) { return launch_r4096_inst<true, false, false, false, true>(Y, X, win, tw, a, s, nullptr); }
+    return launch_r4096_inst<false, false, false, false, true>(Y, X, win, tw, a, s, nullptr);
 }
 
 }  // namespace dsp

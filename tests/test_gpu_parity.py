@@ -9,6 +9,8 @@ a bin that is pure rounding residue, such as DC after mean removal, may be exact
 implementation and 1e-12 of the maximum in the other); log of an all-zero frame must be -inf
 (test_log_of_silence_is_minus_inf).  Copies (framing) are bit-exact.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -1363,3 +1365,41 @@ def test_complex_spectrogram(O, D, dt):
                 assert np.all(Yh[b][:, 0].imag == 0) and np.all(Yh[b][:, -1].imag == 0)
                 mag2 = (Yh[b].real.astype(np.float64) ** 2 + Yh[b].imag.astype(np.float64) ** 2) / (k * k)
                 assert O.normalised_err(mag2.astype(dt), Ph[b]) <= tol
+
+
+def test_complex_spectrogram_4096(O, D):
+    """The 4096-point kernel's complex form: its frame loop (full and short windows) and its run loop (forced at a small
+    size), where the frame in the registers is rotated by a multiple of a quarter of its length and the complex form turns
+    every bin back by the matching power of i."""
+    import torch
+    rng = np.random.default_rng(43)
+    old = os.environ.get("DSP_R4096_MIN_RUNS")
+    try:
+        for (B, N, L, hop, run) in ((1, 40000, 4096, 1024, False), (2, 30000, 3000, 750, False), (2, 1024 * 150 + 5, 4096, 1024, True),
+                                    (3, 4096 * 9, 4096, 2048, False)):
+            if run:
+                os.environ["DSP_R4096_MIN_RUNS"] = "1"
+            elif "DSP_R4096_MIN_RUNS" in os.environ:
+                del os.environ["DSP_R4096_MIN_RUNS"]
+            x = (rng.standard_normal((B, N)) * 0.1).astype(np.float32)
+            win = D.blackmanharris(L, np.float32)
+            xd, wd = torch.from_numpy(x).cuda(), torch.from_numpy(win).cuda()
+            Y = D.stft_cplx_dev(xd, wd, hop, nfft=4096, sc=True)
+            P = D.stft_dev(xd, wd, hop, nfft=4096)
+            torch.cuda.synchronize()
+            Yh, Ph = Y.cpu().numpy(), P.cpu().numpy()
+            for b in range(B):
+                rc, fr = O.frame_univar(x[b], L, hop, False)
+                rc2, ref = O.fft_r2hc(np.ascontiguousarray(fr * win[None, :]).astype(np.float64), 1, 4096, False, True, exact=False)
+                assert rc == 0 and rc2 == 0 and Yh[b].shape == ref.shape
+                scale = np.abs(ref).max(axis=1, keepdims=True)
+                err = float((np.abs(Yh[b] - ref) / np.maximum(scale, 1e-300)).max())
+                assert err <= 3e-6, ((B, N, L, hop, run), err)
+                assert np.all(Yh[b][:, 0].imag == 0) and np.all(Yh[b][:, -1].imag == 0)
+                mag2 = (Yh[b].real.astype(np.float64) ** 2 + Yh[b].imag.astype(np.float64) ** 2) * (2.0 * 4096)
+                assert O.normalised_err(mag2.astype(np.float32), Ph[b]) <= TOL[np.dtype(np.float32)]
+    finally:
+        if old is None:
+            os.environ.pop("DSP_R4096_MIN_RUNS", None)
+        else:
+            os.environ["DSP_R4096_MIN_RUNS"] = old

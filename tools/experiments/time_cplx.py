@@ -37,3 +37,9 @@ win = torch.from_numpy(dsp_amd.hann(200)).cuda()
 y = dsp_amd.stft_cplx_dev(x, win, 80, nfft=256)
 ms = t(lambda: dsp_amd.stft_cplx_dev(x, win, 80, nfft=256, out=y))
 print('float32 nfft 256 L 200 hop 80: %.3f ms  %.1f %% of 8 TB/s' % (ms, 1024 * y.shape[1] * (80 + 258) * 4 / ms / 8e9 * 100), flush=True)
+x = torch.randn((8, 43200000), device='cuda') * 0.1
+win = torch.from_numpy(dsp_amd.blackmanharris(4096)).cuda()
+y = dsp_amd.stft_cplx_dev(x, win, 1024, nfft=4096)
+ms = t(lambda: dsp_amd.stft_cplx_dev(x, win, 1024, nfft=4096, out=y), 10)
+mt = t(lambda: torch.stft(x, 4096, hop_length=1024, window=win, center=True, pad_mode='reflect', return_complex=True), 4)
+print('float32 nfft 4096 hop 1024: %.3f ms  %.1f %% of 8 TB/s   torch.stft: %.3f ms' % (ms, 8 * y.shape[1] * (1024 + 4098) * 4 / ms / 8e9 * 100, mt), flush=True)

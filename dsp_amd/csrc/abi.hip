@@ -111,7 +111,8 @@ int get_twiddles(const char *fn, int dev, size_t nfft, int full, const T *&out)
         h[2 * k + 1] = (T)(-sinl(a));
     }
     void *p = nullptr;
-    HIPCHK(fn, hipMalloc(&p, 2 * cnt * sizeof(T)));
+    // (at least 1 KiB: the span-staging kernels issue placeholder loads of the table's first KiB)
+    HIPCHK(fn, hipMalloc(&p, std::max(2 * cnt * sizeof(T), (size_t)1024)));
     HIPCHK(fn, hipMemcpy(p, h.data(), 2 * cnt * sizeof(T), hipMemcpyHostToDevice));
     st.tw[key] = p;
     out = static_cast<const T *>(p);
@@ -268,7 +269,7 @@ int family_of(size_t nfft)
     if (nfft == 512 && !tl_force_generic) { return 3; }
     if (nfft == 4096 && sizeof(T) == 4 && !tl_force_generic) { return 4; }
     if ((nfft == 1024 || nfft == 2048) && sizeof(T) == 4 && !tl_force_generic) { return 6; }
-    if (nfft == 256 && sizeof(T) == 4 && !tl_force_generic) { return 7; }
+    if ((nfft == 256 || nfft == 128 || nfft == 64) && sizeof(T) == 4 && !tl_force_generic) { return 7; }
     if (!tl_force_generic && nfft <= (1u << 20)) {
         FrameDesc probe{};
         probe.nfft = (int)nfft; probe.L = 1;
@@ -1221,7 +1222,7 @@ int stft_cplx_dev(const char *fn, T *Yd, const T *Xd, const T *wd, size_t B, siz
             HIPCHK(fn, launch_stft_r4096_cplx(Yd, Xd, wd, tw, d, scale, s));
             return 0;
         }
-        if (nfft == 256 && !tl_force_generic && r256_cplx_supported(d)) {
+        if ((nfft == 256 || nfft == 128 || nfft == 64) && !tl_force_generic && r256_cplx_supported(d)) {
             if (get_twiddles<T>(fn, dev, nfft, 0, tw)) { return 1; }
             HIPCHK(fn, launch_stft_r256_cplx(Yd, Xd, wd, tw, d, scale, s));
             return 0;

@@ -1,4 +1,8 @@
-// Fused STFT kernel for nfft = 256, float32, equally spaced frames (gfx950).
+// Fused STFT kernel for nfft = 256, 128 and 64, float32 (gfx950).
+//
+// The kernel is written for CL lanes per frame, nfft = 32 CL: CL = 8 (nfft 256, described below), 4 (nfft 128: 64 complex
+// points as 16 x 4 on 4 lanes, 16 frames per wave and step, pass 2 four 4-point FFTs per lane) and 2 (nfft 64: 16 x 2 on
+// 2 lanes, 32 frames per step, pass 2 eight 2-point butterflies per lane).
 //
 // A frame's 256 reals are 128 complex points z_n = x_2n + i x_2n+1, transformed as 16 x 8 on 8 lanes:
 //   pass 1  lane (frame f, column n2 = j < 8) holds the rows n1 < 16, z_(j + 8 n1): window (taps in registers),
@@ -36,8 +40,11 @@ struct R256Args {
     float cscale;         // complex form: factor on every output value
 };
 
-constexpr int R256_FP = 152;                         // complex slots per frame in the exchange tile (16 rows, pitch 9, + 8)
-constexpr int R256_TILE = 8 * R256_FP * 2;           // floats of a wave's exchange tile / row staging
+// Exchange tile of a wave: per frame 16 rows k1 of CL values at row pitch CL + 1; the frame pitch (complex slots) makes
+// both the writes of pass 1 (lane (f, j) at f FP + j + k1 (CL + 1)) and the reads of pass 2 (f FP + (j + CL r)(CL + 1) + n2)
+// fall on 32 different 8-byte banks over a half-wave.
+__host__ __device__ constexpr int r256_fp(int CL) { return CL == 8 ? 152 : CL == 4 ? 84 : 50; }
+__host__ __device__ constexpr int r256_tile(int CL) { return (64 / CL) * r256_fp(CL) * 2; }   // floats: exchange tile / row staging
 constexpr int R256_WAVES = 8;
 
 #ifndef R256_MINIMAL
@@ -51,6 +58,14 @@ __device__ __forceinline__ float r256_half_mirror(float v)   // lane 7 - i of th
 __device__ __forceinline__ float r256_shr1(float v)          // lane i - 1 of the same row of 16 (lane 0 of a row: 0)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
+}
+
+// lane (CL - j) % CL of the lane's group of CL (a frame's lanes); the value that lane j == 0 gets is not used for CL == 8
+template <int CL> __device__ __forceinline__ float r256_grp_neg(float v)
+{
+    if constexpr (CL == 8) { return r256_shr1(r256_half_mirror(v)); }
+    else if constexpr (CL == 4) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x6C, 0xf, 0xf, true)); }   // quad_perm:[0,3,2,1]
+    else { return v; }
 }
 
 // forward 8-point DFT; X[k] is left in a[slot8(k)]
@@ -71,35 +86,46 @@ __device__ __forceinline__ void dft8c(cx<float> (&a)[8])
     }
 }
 
-// CPLX: the rows are the complex spectra (129 interleaved (re, im) pairs per frame, the imaginary parts of the first and
+// forward CL-point DFT of a row of pass 2; X[k] is left in a[r256_slot<CL>(k)]
+template <int CL> __host__ __device__ constexpr int r256_slot(int k) { return CL == 8 ? slot8(k) : k; }
+template <int CL> __device__ __forceinline__ void r256_dft_row(cx<float> (&a)[CL])
+{
+    if constexpr (CL == 8) { dft8c(a); }
+    else if constexpr (CL == 4) { dft4c<float>(a[0], a[1], a[2], a[3]); }
+    else { const cx<float> t = a[0]; a[0] = t + a[1]; a[1] = t - a[1]; }
+}
+
+// CPLX: the rows are the complex spectra (nfft/2 + 1 interleaved (re, im) pairs per frame, the imaginary parts of the first and
 // last zero: window_univar followed by fft_fftw_r2hc, reference c/window_univar.c:41-89, c/fft.fftw.r2hc.c:69-78) instead of
 // their powers.
-template <int NR, bool MN0, bool EPI, int SPAN, bool ALN, bool CPLX = false>
+template <int CL, int NR, bool MN0, bool EPI, int SPAN, bool ALN, bool CPLX = false>
 __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__restrict__ Y, const float *__restrict__ X,
                                                                        const float *__restrict__ win, const float *__restrict__ tw,
                                                                        const R256Args a)
 {
     using C = cx<float>;
     typedef float f2e __attribute__((ext_vector_type(2), aligned(4)));
-    constexpr int M = 128, F = 129, FPS = 8, NWV = R256_WAVES, NV = SPAN / 256;
-    constexpr int WAVE_LDS = R256_TILE + SPAN;
+    constexpr int M = 16 * CL, F = M + 1, FPS = 64 / CL, RW = 16 / CL, NWV = R256_WAVES, NV = SPAN / 256;
+    constexpr int RP = CL + 1, FP = r256_fp(CL), TILE = r256_tile(CL);
+    constexpr int WAVE_LDS = TILE + SPAN;
+    static_assert(CL == 8 || CL == 4 || CL == 2, "8, 4 or 2 lanes per frame");
     constexpr int ROWF = CPLX ? 2 * F : F;                 // floats of an output row
     constexpr int NVI = (FPS * ROWF + 255) / 256;          // whole-vector wave stores of a step's block of rows
-    static_assert(FPS * ROWF + 3 <= R256_TILE, "row staging fits the tile");
+    static_assert(FPS * ROWF + 3 <= TILE && 16 * RP <= FP, "row staging and a frame's rows fit the tile");
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int f = lane >> 3, j = lane & 7;
+    const int f = lane / CL, j = lane % CL;
     const int L = a.L;
 
     float *xs = reinterpret_cast<float *>(smem_raw) + wv * WAVE_LDS;   // exchange tile, then row staging
     float2 *ex = reinterpret_cast<float2 *>(xs);
-    float *slot = xs + R256_TILE;                                      // the span
+    float *slot = xs + TILE;                                      // the span
     float *dummy = reinterpret_cast<float *>(smem_raw) + NWV * WAVE_LDS;   // 1 KiB that placeholder LDS-DMA loads write
     unsigned *ticket = reinterpret_cast<unsigned *>(dummy + 256);
 
     // ---- per-lane constants ----
-    C twd[16];                                             // W128^(j k1) = W256^(2 j k1), j k1 <= 105
+    C twd[16];                                             // W_M^(j k1) = W_nfft^(2 j k1), 2 j k1 < nfft
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) {
         int idx = 2 * j * k1;
@@ -110,23 +136,25 @@ __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__
     C hw[NR];                                              // halved window taps of the lane's column
 #pragma unroll
     for (int n1 = 0; n1 < NR; ++n1) {
-        const int l = 16 * n1 + 2 * j;
+        const int l = 2 * CL * n1 + 2 * j;
         hw[n1] = C{(l < L) ? 0.5f * win[l] : 0.f, (l + 1 < L) ? 0.5f * win[l + 1] : 0.f};
     }
-    C owa[4], owb[4];                                      // -i W256^K for K = j + 16 k2 and K = j + 8 + 16 k2, k2 < 4
+    C ow[RW][CL / 2];                                      // -i W_nfft^K for K = j + CL r + 16 k2, k2 < CL/2
 #pragma unroll
-    for (int k2 = 0; k2 < 4; ++k2) {
-        const int Ka = j + 16 * k2, Kb = Ka + 8;
-        owa[k2] = C{tw[2 * Ka + 1], -tw[2 * Ka]};
-        owb[k2] = C{tw[2 * Kb + 1], -tw[2 * Kb]};
+    for (int r = 0; r < RW; ++r) {
+#pragma unroll
+        for (int k2 = 0; k2 < CL / 2; ++k2) {
+            const int K = j + CL * r + 16 * k2;
+            ow[r][k2] = C{tw[2 * K + 1], -tw[2 * K]};
+        }
     }
     if (tid == 0) { *ticket = NWV; }
     __syncthreads();
 
     const int reach = a.tbl ? a.reach : (FPS - 1) * a.stp;
-    const int need = reach + min(L, 16 * NR);              // samples of a span that pass 1 uses
+    const int need = reach + min(L, 2 * CL * NR);             // samples of a span that pass 1 uses
     const float *xrow = slot + f * a.stp + 2 * j;
-    // Start of the span of the step at frame w_ (wave-uniform).  Table form: the starts of the step's 8 frames by
+    // Start of the span of the step at frame w_ (wave-uniform).  Table form: the starts of the step's frames by
     // scalar loads (a vector load would put the compiler's own wait for ALL outstanding memory operations, the row
     // stores included, in front of the span fetch), and xrow for that step: called when pass 1 is done with the last one.
     auto step_start = [&](const int w_) {
@@ -202,10 +230,10 @@ __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__
         for (int n1 = 0; n1 < 16; ++n1) {
             if (n1 < NR) {
                 C v;
-                if constexpr (ALN) { const float2 t = *reinterpret_cast<const float2 *>(xrow + 16 * n1); v = C{t.x, t.y}; }
-                else { const f2e t = *reinterpret_cast<const f2e *>(xrow + 16 * n1); v = C{t.x, t.y}; }
+                if constexpr (ALN) { const float2 t = *reinterpret_cast<const float2 *>(xrow + 2 * CL * n1); v = C{t.x, t.y}; }
+                else { const f2e t = *reinterpret_cast<const f2e *>(xrow + 2 * CL * n1); v = C{t.x, t.y}; }
                 if (NR == 16 || n1 == NR - 1) {            // rows that may reach past the window: keep that data out (0 * NaN)
-                    const int l = 16 * n1 + 2 * j;
+                    const int l = 2 * CL * n1 + 2 * j;
                     v.x = (l < L) ? v.x : 0.f;
                     v.y = (l + 1 < L) ? v.y : 0.f;
                 }
@@ -219,12 +247,13 @@ __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__
 #pragma unroll
             for (int n1 = 1; n1 < NR; ++n1) { acc += zz[n1]; }
             float sum = acc.x + acc.y;
-            sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
+#pragma unroll
+            for (int m = 1; m < CL; m *= 2) { sum += __shfl_xor(sum, m); }
             const float mean = sum / (float)L;
 #pragma unroll
             for (int n1 = 0; n1 < NR; ++n1) {
                 if (NR == 16 || n1 == NR - 1) {
-                    const int l = 16 * n1 + 2 * j;
+                    const int l = 2 * CL * n1 + 2 * j;
                     zz[n1] -= C{(l < L) ? mean : 0.f, (l + 1 < L) ? mean : 0.f};
                 } else {
                     zz[n1] -= C{mean, mean};
@@ -240,98 +269,80 @@ __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__
         advance();
         load_span(more ? nxb : xb, step_start(more ? nw : w));
         {
-            float2 *exf = ex + f * R256_FP + j;
+            float2 *exf = ex + f * FP + j;
 #pragma unroll
             for (int k1 = 0; k1 < 16; ++k1) {
                 C v = zz[slot16(k1)];
                 if (k1 > 0) { v = cx_mul<float>(v, twd[k1]); }
-                exf[k1 * 9] = make_float2(v.x, v.y);
+                exf[k1 * RP] = make_float2(v.x, v.y);
             }
         }
         wave_sync();
 
-        // ---- pass 2: the lane's two rows k1 = j (za) and k1 = j + 8 (zb): 8-point FFTs over the columns ----
-        C za[8], zb[8];
-        {
-            const float2 *ra = ex + f * R256_FP + j * 9, *rb = ra + 72;
+        // ---- pass 2: the lane's RW rows k1 = j + CL r: a CL-point FFT over the columns each ----
+        C zr[RW][CL];
 #pragma unroll
-            for (int n2 = 0; n2 < 8; ++n2) { const float2 t = ra[n2]; za[n2] = C{t.x, t.y}; }
+        for (int r = 0; r < RW; ++r) {
+            const float2 *ra = ex + f * FP + (j + CL * r) * RP;
 #pragma unroll
-            for (int n2 = 0; n2 < 8; ++n2) { const float2 t = rb[n2]; zb[n2] = C{t.x, t.y}; }
+            for (int n2 = 0; n2 < CL; ++n2) { const float2 t = ra[n2]; zr[r][n2] = C{t.x, t.y}; }
         }
-        dft8c(za);
-        dft8c(zb);
+#pragma unroll
+        for (int r = 0; r < RW; ++r) { r256_dft_row<CL>(zr[r]); }
 
-        // ---- real-FFT split fused with power.  za[slot8(k2)] = Z[j + 16 k2], zb[slot8(k2)] = Z[j + 8 + 16 k2] (halved).
-        // Partner of K = j + 16 k2:     Z[128 - K] = row b, register 7 - k2, of lane 8 - j   (j = 0: own za[(8 - k2) % 8]);
-        // partner of K = j + 8 + 16 k2: Z[128 - K] = row a, register 7 - k2, of lane 8 - j   (j = 0: own zb[7 - k2]).
-        // With A = Z_K + conj Z_(128-K), B = Z_K - conj Z_(128-K), T = -i W256^K B:
-        // |X_K|^2 = |A + T|^2 and |X_(128-K)|^2 = |A - T|^2.  K < 64 (k2 < 4) covers every pair once; K = 64 pairs with itself.
+        // ---- real-FFT split fused with power.  zr[r][slot(k2)] = Z[K], K = j + CL r + 16 k2 (halved).
+        // Partner Z[M - K]: row 16 - k1 = (CL - j) + CL (RW - 1 - r), register CL - 1 - k2: row RW - 1 - r of lane CL - j;
+        // for j = 0: own row RW - r, register CL - 1 - k2 (r > 0), own row 0, register (CL - k2) % CL (r = 0).
+        // With A = Z_K + conj Z_(M-K), B = Z_K - conj Z_(M-K), T = -i W_nfft^K B:
+        // |X_K|^2 = |A + T|^2 and |X_(M-K)|^2 = |A - T|^2.  K < M/2 (k2 < CL/2) covers every pair once; K = M/2 pairs with itself.
         // the step's block of rows in the output, and how it lies against 16-byte boundaries
         float *yblk = yb + (size_t)w * ROWF;
         const int nout = __builtin_amdgcn_readfirstlane(min(FPS, a.W - w) * ROWF);
         const int head = ring_block_head(yblk);
         const int sh = ring_stage_shift(head);             // value e of the block is staged at xs[sh + e]
+        auto partner = [&](const int r, const int k2) {
+            const C oth = zr[RW - 1 - r][r256_slot<CL>(CL - 1 - k2)];
+            const C own = (r == 0) ? zr[0][r256_slot<CL>((CL - k2) % CL)] : zr[RW - r][r256_slot<CL>(CL - 1 - k2)];
+            const float px = r256_grp_neg<CL>(oth.x), py = r256_grp_neg<CL>(oth.y);
+            return C{(j == 0) ? own.x : px, (j == 0) ? own.y : py};
+        };
         if constexpr (CPLX) {
-            // X_K = A + T, X_(128-K) = conj(A - T), each written to the staging area as soon as it exists; K = 64 is
-            // 2 conj Z_64 (lane j == 0)
+            // X_K = A + T, X_(M-K) = conj(A - T), each written to the staging area as soon as it exists; K = M/2 is
+            // 2 conj Z_(M/2) (lane j == 0)
             const float sc = a.cscale;
-            const C zmid = za[slot8(4)];
-            wave_sync();                                   // every lane has read its tile rows (into za, zb): reuse the region
+            const C zmid = zr[0][r256_slot<CL>(CL / 2)];
+            wave_sync();                                   // every lane has read its tile rows (into zr): reuse the region
             float *pf = xs + sh + f * ROWF;
 #pragma unroll
-            for (int k2 = 0; k2 < 4; ++k2) {
-                auto partner = [&](const C oth, const C own) {
-                    const float px = r256_shr1(r256_half_mirror(oth.x)), py = r256_shr1(r256_half_mirror(oth.y));
-                    return C{(j == 0) ? own.x : px, (j == 0) ? own.y : py};
-                };
-                const int Ka = j + 16 * k2, Kb = Ka + 8;
-                {
-                    const C z = za[slot8(k2)];
-                    const C m = partner(zb[slot8(7 - k2)], za[slot8((8 - k2) & 7)]);
+            for (int r = 0; r < RW; ++r) {
+#pragma unroll
+                for (int k2 = 0; k2 < CL / 2; ++k2) {
+                    const int K = j + CL * r + 16 * k2;
+                    const C z = zr[r][r256_slot<CL>(k2)];
+                    const C m = partner(r, k2);
                     const C A = cx_add_conj<float>(z, m), B = cx_sub_conj<float>(z, m);
-                    const C Tw = cx_mul<float>(B, owa[k2]);
+                    const C Tw = cx_mul<float>(B, ow[r][k2]);
                     const C u = A + Tw, v = A - Tw;
-                    const bool edge = (j == 0) && k2 == 0;     // bins 0 and 128: imaginary parts zero
-                    pf[2 * Ka] = sc * u.x; pf[2 * Ka + 1] = edge ? 0.f : sc * u.y;
-                    pf[2 * (M - Ka)] = sc * v.x; pf[2 * (M - Ka) + 1] = edge ? 0.f : -sc * v.y;
-                }
-                {
-                    const C z = zb[slot8(k2)];
-                    const C m = partner(za[slot8(7 - k2)], zb[slot8(7 - k2)]);
-                    const C A = cx_add_conj<float>(z, m), B = cx_sub_conj<float>(z, m);
-                    const C Tw = cx_mul<float>(B, owb[k2]);
-                    const C u = A + Tw, v = A - Tw;
-                    pf[2 * Kb] = sc * u.x; pf[2 * Kb + 1] = sc * u.y;
-                    pf[2 * (M - Kb)] = sc * v.x; pf[2 * (M - Kb) + 1] = -sc * v.y;
+                    const bool edge = (j == 0) && r == 0 && k2 == 0;     // bins 0 and M: imaginary parts zero
+                    pf[2 * K] = sc * u.x; pf[2 * K + 1] = edge ? 0.f : sc * u.y;
+                    pf[2 * (M - K)] = sc * v.x; pf[2 * (M - K) + 1] = edge ? 0.f : -sc * v.y;
                 }
             }
             if (j == 0) { pf[M] = 2.0f * sc * zmid.x; pf[M + 1] = -2.0f * sc * zmid.y; }
             wave_sync();
         } else {
-            float pw[16];                                      // [k2]: P[Ka], [4 + k2]: P[128 - Ka], [8 + k2]: P[Kb], [12 + k2]: P[128 - Kb]
-            float pmid = 4.0f * cx_norm<float>(za[slot8(4)]);  // K = 64: lane j == 0 only
+            float pw[16];                                      // [(r CL/2 + k2) 2]: P[K], [.. + 1]: P[M - K]
+            float pmid = 4.0f * cx_norm<float>(zr[0][r256_slot<CL>(CL / 2)]);  // K = M/2: lane j == 0 only
 #pragma unroll
-            for (int k2 = 0; k2 < 4; ++k2) {
-                auto partner = [&](const C oth, const C own) {
-                    const float px = r256_shr1(r256_half_mirror(oth.x)), py = r256_shr1(r256_half_mirror(oth.y));
-                    return C{(j == 0) ? own.x : px, (j == 0) ? own.y : py};
-                };
-                {
-                    const C z = za[slot8(k2)];
-                    const C m = partner(zb[slot8(7 - k2)], za[slot8((8 - k2) & 7)]);
+            for (int r = 0; r < RW; ++r) {
+#pragma unroll
+                for (int k2 = 0; k2 < CL / 2; ++k2) {
+                    const C z = zr[r][r256_slot<CL>(k2)];
+                    const C m = partner(r, k2);
                     const C A = cx_add_conj<float>(z, m), B = cx_sub_conj<float>(z, m);
-                    const C Tw = cx_mul<float>(B, owa[k2]);
-                    pw[k2] = cx_norm<float>(A + Tw);
-                    pw[4 + k2] = cx_norm<float>(A - Tw);
-                }
-                {
-                    const C z = zb[slot8(k2)];
-                    const C m = partner(za[slot8(7 - k2)], zb[slot8(7 - k2)]);
-                    const C A = cx_add_conj<float>(z, m), B = cx_sub_conj<float>(z, m);
-                    const C Tw = cx_mul<float>(B, owb[k2]);
-                    pw[8 + k2] = cx_norm<float>(A + Tw);
-                    pw[12 + k2] = cx_norm<float>(A - Tw);
+                    const C Tw = cx_mul<float>(B, ow[r][k2]);
+                    pw[(r * (CL / 2) + k2) * 2] = cx_norm<float>(A + Tw);
+                    pw[(r * (CL / 2) + k2) * 2 + 1] = cx_norm<float>(A - Tw);
                 }
             }
             if (EPI) {
@@ -342,19 +353,20 @@ __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__
             {
                 float *pf = xs + sh + f * F;
 #pragma unroll
-                for (int k2 = 0; k2 < 4; ++k2) {
-                    const int Ka = j + 16 * k2, Kb = Ka + 8;
-                    pf[Ka] = pw[k2];
-                    pf[M - Ka] = pw[4 + k2];
-                    pf[Kb] = pw[8 + k2];
-                    pf[M - Kb] = pw[12 + k2];
+                for (int r = 0; r < RW; ++r) {
+#pragma unroll
+                    for (int k2 = 0; k2 < CL / 2; ++k2) {
+                        const int K = j + CL * r + 16 * k2;
+                        pf[K] = pw[(r * (CL / 2) + k2) * 2];
+                        pf[M - K] = pw[(r * (CL / 2) + k2) * 2 + 1];
+                    }
                 }
                 if (j == 0) { pf[M / 2] = pmid; }
             }
             wave_sync();
         }
 
-        // ---- six stores: five of whole 16-byte vectors, one for the values before and after them.  Surplus
+        // ---- NVI + 1 stores: NVI of whole 16-byte vectors, one for the values before and after them.  Surplus
         // lanes repeat a valid store (same value to the same address).
         ring_store_rows<NVI>(yblk, xs + sh, head, nout, lane);
         if (!more) { break; }
@@ -366,88 +378,102 @@ __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-// nfft 256; frames at ss0 + w * hop, or a table of frame starts that never decrease and are read where they start;
-// the 8 frames of a step inside 2048 samples; every index of one signal's input and output inside 31 bits
+// Largest span a wave's LDS share holds beside its tile: 8 waves x (tile + span) floats + 1 KiB inside 160 KiB
+__host__ __device__ constexpr int r256_max_span(int CL) { return CL == 2 ? 1536 : 2048; }
+// frames of a step, and how many times tbl_reach (a bound on the distance of frames w and w + 3) bounds the distance of
+// the first and last frame of a step
+static int r256_fps(int nfft) { return 64 / (nfft / 32); }
+static int r256_reach_mult(int nfft) { return (r256_fps(nfft) - 1 + 2) / 3; }
+
+// nfft 256, 128 or 64; frames at ss0 + w * hop, or a table of frame starts that never decrease and are read where they
+// start; the frames of a step inside the largest span; every index of one signal's input and output inside 31 bits
 bool r256_supported(const FrameDesc &d)
 {
-    // (tbl_reach bounds the distance of frames w and w + 3: three times that bounds the distance of frames w and w + 7)
-    const bool placed = d.tbl ? (d.tbl_reach >= 0 && 3ll * d.tbl_reach + 256 <= 2048) : (d.stp >= 1 && 7ll * d.stp + 256 <= 2048);
-    return d.nfft == 256 && placed && d.L >= 1 && d.L <= 256 &&
-           d.N < (1ll << 31) - 4096 && (long long)d.W * 129 < (1ll << 30) && (long long)d.B * d.W < (1ll << 30) &&
+    if (d.nfft != 256 && d.nfft != 128 && d.nfft != 64) { return false; }
+    const int fps = r256_fps(d.nfft), span = r256_max_span(d.nfft / 32);
+    const bool placed = d.tbl ? (d.tbl_reach >= 0 && (long long)r256_reach_mult(d.nfft) * d.tbl_reach + d.nfft <= span)
+                              : (d.stp >= 1 && (long long)(fps - 1) * d.stp + d.nfft <= span);
+    return placed && d.L >= 1 && d.L <= d.nfft &&
+           d.N < (1ll << 31) - 4096 && (long long)d.W * (d.nfft / 2 + 1) < (1ll << 30) && (long long)d.B * d.W < (1ll << 30) &&
            d.ss0 > -(1ll << 30) && d.ss0 < (1ll << 30) && d.rd_shift >= 0 && d.rd_shift < (1ll << 30);
 }
 
-template <int NR, bool MN0, bool EPI, int SPAN, bool ALN, bool CPLX = false>
+template <int CL, int NR, bool MN0, bool EPI, int SPAN, bool ALN, bool CPLX = false>
 static hipError_t launch_r256_inst(float *Y, const float *X, const float *win, const float *tw, const R256Args &a, hipStream_t s)
 {
-    const size_t lds = ((size_t)R256_WAVES * (R256_TILE + SPAN) + 256) * sizeof(float) + 16;
+    static_assert(SPAN <= r256_max_span(CL), "span too large for the LDS");
+    const size_t lds = ((size_t)R256_WAVES * (r256_tile(CL) + SPAN) + 256) * sizeof(float) + 16;
     static LdsGrant grant;
-    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r256_kernel<NR, MN0, EPI, SPAN, ALN, CPLX>), lds, grant); e != hipSuccess) { return e; }
+    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r256_kernel<CL, NR, MN0, EPI, SPAN, ALN, CPLX>), lds, grant); e != hipSuccess) { return e; }
     long long grid = ((long long)a.steps + R256_WAVES - 1) / R256_WAVES;
     if (grid > 256) { grid = 256; }                     // one 8-wave workgroup per CU
     grid = (grid + 7) & ~7ll;                           // whole groups of 8 workgroups (one per XCD)
-    hipLaunchKernelGGL((stft_r256_kernel<NR, MN0, EPI, SPAN, ALN, CPLX>), dim3((unsigned)grid), dim3(64 * R256_WAVES), lds, s, Y, X, win, tw, a);
+    hipLaunchKernelGGL((stft_r256_kernel<CL, NR, MN0, EPI, SPAN, ALN, CPLX>), dim3((unsigned)grid), dim3(64 * R256_WAVES), lds, s, Y, X, win, tw, a);
     return hipGetLastError();
 }
 
-template <int NR, int SPAN, bool ALN>
-static hipError_t launch_r256_shape(float *Y, const float *X, const float *win, const float *tw, const R256Args &a, const FrameDesc &d, hipStream_t s)
+template <int CL, int NR, int SPAN, bool ALN>
+static hipError_t launch_r256_shape(float *Y, const float *X, const float *win, const float *tw, const R256Args &a, const FrameDesc &d, bool cplx, hipStream_t s)
 {
     const bool epi = d.epi.any();
+    if (cplx) { return launch_r256_inst<CL, NR, false, false, SPAN, ALN, true>(Y, X, win, tw, a, s); }
 #if R256_MINIMAL
-    if (!d.mn0 && !epi) { return launch_r256_inst<NR, false, false, SPAN, ALN>(Y, X, win, tw, a, s); }
+    if (!d.mn0 && !epi) { return launch_r256_inst<CL, NR, false, false, SPAN, ALN>(Y, X, win, tw, a, s); }
     return hipErrorInvalidValue;
 #else
-    if (d.mn0) { return epi ? launch_r256_inst<NR, true, true, SPAN, ALN>(Y, X, win, tw, a, s) : launch_r256_inst<NR, true, false, SPAN, ALN>(Y, X, win, tw, a, s); }
-    return epi ? launch_r256_inst<NR, false, true, SPAN, ALN>(Y, X, win, tw, a, s) : launch_r256_inst<NR, false, false, SPAN, ALN>(Y, X, win, tw, a, s);
+    if (d.mn0) { return epi ? launch_r256_inst<CL, NR, true, true, SPAN, ALN>(Y, X, win, tw, a, s) : launch_r256_inst<CL, NR, true, false, SPAN, ALN>(Y, X, win, tw, a, s); }
+    return epi ? launch_r256_inst<CL, NR, false, true, SPAN, ALN>(Y, X, win, tw, a, s) : launch_r256_inst<CL, NR, false, false, SPAN, ALN>(Y, X, win, tw, a, s);
 #endif
+}
+
+template <int CL>
+static hipError_t launch_r256_cl(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, bool cplx, double scale, hipStream_t s)
+{
+    constexpr int FPS = 64 / CL, NFFT = 32 * CL, MAXS = r256_max_span(CL);
+    R256Args a{};
+    a.ldx = d.ldx; a.N = (int)d.N; a.L = d.L; a.W = d.W; a.stp = d.stp; a.ss0 = (int)d.ss0;
+    a.rd_shift = (int)d.rd_shift; a.edge = d.edge; a.epi = d.epi;
+    a.sps = (d.W + FPS - 1) / FPS;
+    a.steps = d.B * a.sps;
+    a.tbl = d.tbl; a.reach = 0;
+    a.cscale = (float)scale;
+    if (d.tbl) {
+        a.stp = 0; a.ss0 = 0; a.rd_shift = 0; a.reach = r256_reach_mult(NFFT) * d.tbl_reach;
+        return launch_r256_shape<CL, 16, MAXS, false>(Y, X, win, tw, a, d, cplx, s);
+    }
+    const int reach = (FPS - 1) * d.stp + NFFT;
+    // windows that leave the last three rows of pass 1 empty (nfft 256: 193 to 208 samples, 200 = 25 ms at 8 kHz)
+    const bool nr13 = d.L > 12 * 2 * CL && d.L <= 13 * 2 * CL;
+    if (d.stp & 1) { return launch_r256_shape<CL, 16, MAXS, false>(Y, X, win, tw, a, d, cplx, s); }
+    if (reach <= 1024) {
+        return nr13 ? launch_r256_shape<CL, 13, 1024, true>(Y, X, win, tw, a, d, cplx, s)
+                    : launch_r256_shape<CL, 16, 1024, true>(Y, X, win, tw, a, d, cplx, s);
+    }
+    if (reach <= 1280) { return launch_r256_shape<CL, 16, 1280, true>(Y, X, win, tw, a, d, cplx, s); }
+    return launch_r256_shape<CL, 16, MAXS, true>(Y, X, win, tw, a, d, cplx, s);
+}
+
+static hipError_t launch_r256_any(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, bool cplx, double scale, hipStream_t s)
+{
+    if (d.nfft == 256) { return launch_r256_cl<8>(Y, X, win, tw, d, cplx, scale, s); }
+    if (d.nfft == 128) { return launch_r256_cl<4>(Y, X, win, tw, d, cplx, scale, s); }
+    return launch_r256_cl<2>(Y, X, win, tw, d, cplx, scale, s);
 }
 
 hipError_t launch_stft_r256(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, hipStream_t s)
 {
-    R256Args a{};
-    a.ldx = d.ldx; a.N = (int)d.N; a.L = d.L; a.W = d.W; a.stp = d.stp; a.ss0 = (int)d.ss0;
-    a.rd_shift = (int)d.rd_shift; a.edge = d.edge; a.epi = d.epi;
-    a.sps = (d.W + 7) / 8;
-    a.steps = d.B * a.sps;
-    a.tbl = d.tbl; a.reach = 0;
-    if (d.tbl) {
-        a.stp = 0; a.ss0 = 0; a.rd_shift = 0; a.reach = 3 * d.tbl_reach;
-        return launch_r256_shape<16, 2048, false>(Y, X, win, tw, a, d, s);
-    }
-    const int reach = 7 * d.stp + 256;
-    // windows of 193 to 208 samples (200: 25 ms at 8 kHz) leave the last three rows of pass 1 empty
-    const bool nr13 = d.L > 192 && d.L <= 208;
-    if (d.stp & 1) { return launch_r256_shape<16, 2048, false>(Y, X, win, tw, a, d, s); }
-    if (reach <= 1024) { return nr13 ? launch_r256_shape<13, 1024, true>(Y, X, win, tw, a, d, s) : launch_r256_shape<16, 1024, true>(Y, X, win, tw, a, d, s); }
-    if (reach <= 1280) { return launch_r256_shape<16, 1280, true>(Y, X, win, tw, a, d, s); }
-    return launch_r256_shape<16, 2048, true>(Y, X, win, tw, a, d, s);
+    return launch_r256_any(Y, X, win, tw, d, false, 0.0, s);
 }
 
-// The complex form: Y[b][w][129] interleaved (re, im) pairs times `scale`; equally spaced frames, no mean removal.
+// The complex form: Y[b][w][nfft/2 + 1] interleaved (re, im) pairs times `scale`; equally spaced frames, no mean removal.
 bool r256_cplx_supported(const FrameDesc &d)
 {
-    return r256_supported(d) && d.tbl == nullptr && !d.mn0 && !d.epi.any() && (long long)d.W * 258 < (1ll << 30);
+    return r256_supported(d) && d.tbl == nullptr && !d.mn0 && !d.epi.any() && (long long)d.W * (d.nfft + 2) < (1ll << 30);
 }
 
 hipError_t launch_stft_r256_cplx(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, double scale, hipStream_t s)
 {
-    R256Args a{};
-    a.ldx = d.ldx; a.N = (int)d.N; a.L = d.L; a.W = d.W; a.stp = d.stp; a.ss0 = (int)d.ss0;
-    a.rd_shift = (int)d.rd_shift; a.edge = d.edge; a.epi = d.epi;
-    a.sps = (d.W + 7) / 8;
-    a.steps = d.B * a.sps;
-    a.tbl = nullptr; a.reach = 0;
-    a.cscale = (float)scale;
-    const int reach = 7 * d.stp + 256;
-    const bool nr13 = d.L > 192 && d.L <= 208;
-    if (d.stp & 1) { return launch_r256_inst<16, false, false, 2048, false, true>(Y, X, win, tw, a, s); }
-    if (reach <= 1024) {
-        return nr13 ? launch_r256_inst<13, false, false, 1024, true, true>(Y, X, win, tw, a, s)
-                    : launch_r256_inst<16, false, false, 1024, true, true>(Y, X, win, tw, a, s);
-    }
-    if (reach <= 1280) { return launch_r256_inst<16, false, false, 1280, true, true>(Y, X, win, tw, a, s); }
-    return launch_r256_inst<16, false, false, 2048, true, true>(Y, X, win, tw, a, s);
+    return launch_r256_any(Y, X, win, tw, d, true, scale, s);
 }
 
 }  // namespace dsp

@@ -241,7 +241,7 @@ int dsp_stft_flt_batch_dev_strided_d (double *Y_dev, const double *X_dev, const 
 /* The complex spectrogram of B signals: the frames of stft (same W, same edge reflection) times the window, then the
  * real FFT of each as fft_fftw_r2hc_s/_d returns it: Y[b][w][F] interleaved (re, im) pairs, F = nfft/2+1, the imaginary
  * parts of bins 0 and nfft/2 zero; sc != 0 scales by 1/sqrt(2 nfft) (reference c/window_univar.c:41-89 followed by
- * c/fft.fftw.r2hc.c:24-109 along the frames, fused).  nfft 512 with hop <= 512 and float32 nfft 256 / 1024 / 2048 / 4096 run on the
+ * c/fft.fftw.r2hc.c:24-109 along the frames, fused).  nfft 512 with hop <= 512 and float32 nfft 64 / 128 / 256 / 1024 / 2048 / 4096 run on the
  * fused kernels (the rows leave as complex values instead of powers), anything else on the unfused kernels. */
 int dsp_stft_cplx_batch_dev_s (float *Y_dev, const float *X_dev, const float *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int sc, void *stream);
 int dsp_stft_cplx_batch_dev_d (double *Y_dev, const double *X_dev, const double *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int sc, void *stream);
@@ -306,7 +306,7 @@ int dsp_fft_power_dev_z (double *Y_dev, const double *X_dev, const size_t N, voi
 /* Which kernel family the fused path would use for (nfft, element size 4 or 8):
  * 0 = none (invalid), 1 = direct DFT (nfft not a power of two), 2 = generic power-of-two,
  * 3 = register-resident 512-point, 4 = register-resident 4096-point (float32), 5 = the other powers of two from 16
- * to 8192 (float32) / 4096 (float64), 6 = 1024- and 2048-point (float32), 7 = 256-point (float32).  Families 6 and 7
+ * to 8192 (float32) / 4096 (float64), 6 = 1024- and 2048-point (float32), 7 = 64-, 128- and 256-point (float32).  Families 6 and 7
  * take frames (equally spaced, or the stft_flt framing of any hop) that keep a step (2, 1 and 8 frames) inside 2048
  * samples; other framings of those lengths run on family 5.  For tests and benchmarks. */
 int dsp_stft_kernel_family (const size_t nfft, const size_t elem_size);

@@ -156,7 +156,7 @@ def test_both_power_of_two_families_agree_with_oracle(O, D, dt):
 
 
 def test_256_1024_2048_kernels_agree_with_oracle(O, D):
-    """nfft 256 (family 7), 1024 and 2048 (family 6), float32, equally spaced frames, have kernels of their own: full, short and
+    """nfft 64, 128 and 256 (family 7), 1024 and 2048 (family 6), float32, have kernels of their own: full, short and
     odd windows, hops of every alignment up to the span limit and past it (where the family-5 kernel takes over),
     odd frame counts (a last step with one frame), a signal shorter than the window, every flag, both edge
     rules, and outputs that start 4, 8 and 12 bytes off a 16-byte boundary."""
@@ -164,14 +164,19 @@ def test_256_1024_2048_kernels_agree_with_oracle(O, D):
     dt = np.float32
     assert D.kernel_family(1024, dt) == 6 and D.kernel_family(2048, dt) == 6 and D.kernel_family(1024, np.float64) == 5
     assert D.kernel_family(256, dt) == 7 and D.kernel_family(256, np.float64) == 5
-    shapes = [(256, 256, 64, (0, 0, 0)), (256, 200, 80, (1, 0, 0)), (256, 255, 33, (0, 1, 0)), (256, 129, 256, (1, 1, 1)), (256, 208, 146, (0, 0, 1)),
+    assert D.kernel_family(128, dt) == 7 and D.kernel_family(64, dt) == 7 and D.kernel_family(32, dt) == 5 and D.kernel_family(128, np.float64) == 5
+    shapes = [(128, 128, 32, (0, 0, 0)), (128, 100, 40, (1, 0, 0)), (128, 127, 17, (0, 1, 0)), (128, 65, 128, (1, 1, 1)), (128, 104, 73, (0, 0, 1)),
+              (128, 97, 129, (0, 0, 0)), (128, 2, 1, (1, 0, 0)), (128, 128, 64, (0, 0, 0)),
+              (64, 64, 16, (0, 0, 0)), (64, 50, 20, (1, 0, 0)), (64, 63, 9, (0, 1, 0)), (64, 33, 47, (1, 1, 1)), (64, 52, 48, (0, 0, 1)),
+              (64, 49, 64, (0, 0, 0)), (64, 2, 1, (1, 0, 0)), (64, 64, 32, (0, 1, 1)),
+              (256, 256, 64, (0, 0, 0)), (256, 200, 80, (1, 0, 0)), (256, 255, 33, (0, 1, 0)), (256, 129, 256, (1, 1, 1)), (256, 208, 146, (0, 0, 1)),
               (256, 193, 257, (0, 0, 0)), (256, 2, 1, (1, 0, 0)),
               (1024, 1024, 256, (0, 0, 0)), (1024, 1024, 255, (1, 0, 0)), (1024, 800, 200, (0, 1, 0)), (1024, 513, 1024, (1, 1, 1)),
               (1024, 1000, 1025, (0, 0, 0)), (1024, 3, 77, (1, 0, 1)), (1024, 1024, 1, (0, 0, 0)),
               (2048, 2048, 512, (0, 0, 0)), (2048, 2047, 441, (1, 0, 0)), (2048, 1200, 300, (0, 1, 1)), (2048, 1025, 5000, (1, 1, 0)),
               (2048, 2048, 1, (0, 0, 1))]
     for (nfft, L, stp, flags) in shapes:
-        for N in ((12 * nfft + 77) if stp > 1 else nfft + 300, L // 2 + 1):
+        for N in (max(12 * nfft + 77, 3001) if stp > 1 else nfft + 300, L // 2 + 1):
             x = signal(nfft + N + stp, N, dt) + dt(0.15)
             win = D.povey(L, dt)
             for snip in (0, 1):
@@ -182,7 +187,8 @@ def test_256_1024_2048_kernels_agree_with_oracle(O, D):
                 Y = D.stft(x, win, stp, bool(snip), *[bool(f) for f in flags], nfft=nfft)
                 check_spec(O, Y, Yref.astype(dt), flags[1], flags[2])
     # rows that start off 16-byte boundaries, several signals, odd and even frame counts
-    for (nfft, stp, N) in [(256, 80, 5000), (256, 64, 4157), (1024, 256, 9000), (1024, 300, 9301), (2048, 512, 20000)]:
+    for (nfft, stp, N) in [(64, 16, 3000), (64, 20, 2777), (128, 40, 5000), (128, 32, 4157),
+                           (256, 80, 5000), (256, 64, 4157), (1024, 256, 9000), (1024, 300, 9301), (2048, 512, 20000)]:
         xs = np.stack([signal(10 * k + nfft, N, dt) for k in range(3)])
         win = D.hann(nfft, dt)
         want = np.stack([O.stft(r.astype(np.float64), win.astype(np.float64), stp, nfft, 0, exact=False)[1] for r in xs]).astype(dt)
@@ -196,7 +202,7 @@ def test_256_1024_2048_kernels_agree_with_oracle(O, D):
             assert float(buf[:off].sum()) == 7.0 * off and bool((buf[off + want.size:] == 7.0).all())   # nothing outside the rows
     # a full grid of workgroups: every launch gives the same bits (the span slots are refilled behind the reads of the
     # step before), and interior frames do not depend on where a signal lies in the batch
-    for (nfft, stp) in [(256, 80), (1024, 256), (2048, 512)]:
+    for (nfft, stp) in [(64, 16), (128, 40), (256, 80), (1024, 256), (2048, 512)]:
         xd = torch.randn((64, 1 << 20), device="cuda", generator=torch.Generator(device="cuda").manual_seed(nfft))
         wd = torch.from_numpy(D.hann(nfft, dt)).cuda()
         y0 = D.stft_dev(xd, wd, stp, nfft=nfft)
@@ -211,12 +217,15 @@ def test_256_1024_2048_kernels_agree_with_oracle(O, D):
         del xd, y0, y1
     # zero edges and a first frame off the signal (stft_flt with an integral hop); a non-integral hop goes to family 5
     x = signal(78, 30000, dt)
-    for nfft in (256, 1024, 2048):
+    # (the hops that scale with nfft stay inside the span limits of the small kernels: integral ones by hop, the others by
+    # a table of frame starts)
+    for nfft in (64, 128, 256, 1024, 2048):
         win = D.blackmanharris(nfft, dt)
         for intended in (False, True):
             D.set_flt_mode(intended)
             try:
-                for (c0, stp, W) in [(0.0, 256.0, 31), (700.0, 300.0, 40), (-1500.0, 512.0, 20), (100.0, 250.5, 20)]:
+                for (c0, stp, W) in [(0.0, 256.0, 31), (700.0, 300.0, 40), (-1500.0, 512.0, 20), (100.0, 250.5, 20),
+                                     (0.0, nfft / 4.0, 75), (-3.0 * nfft, nfft / 2.0, 41), (100.0, nfft / 4.0 + 0.5, 67), (29000.0, nfft / 4.0 + 0.25, 70)]:
                     rc, Yref = O.stft_flt(x.astype(np.float64), win.astype(np.float64), W, c0, stp, nfft, 0, 0, 0, intended=intended, exact=False)
                     assert rc == 0
                     Y = D.stft_flt(x, win, W, c0, stp, nfft=nfft)
@@ -1342,7 +1351,10 @@ def test_complex_spectrogram(O, D, dt):
              (2, 20000, 800, 200, 1024, False), (3, 9000, 1024, 512, 1024, True), (2, 30000, 2048, 512, 2048, False), (2, 12001, 1200, 301, 2048, False),
              (1, 9001, 1024, 255, 1024, False), (5, 4099, 2048, 1024, 2048, False),
              # the 256-point kernel's (float32)
-             (3, 8000, 200, 80, 256, False), (2, 8001, 256, 81, 256, True), (4, 3001, 256, 128, 256, False), (1, 9000, 130, 200, 256, False)]
+             (3, 8000, 200, 80, 256, False), (2, 8001, 256, 81, 256, True), (4, 3001, 256, 128, 256, False), (1, 9000, 130, 200, 256, False),
+             # the 128- and 64-point forms of that kernel
+             (3, 8000, 100, 40, 128, False), (2, 8001, 128, 41, 128, True), (4, 3001, 128, 64, 128, False), (1, 9000, 70, 128, 128, False),
+             (3, 4000, 50, 20, 64, False), (2, 4001, 64, 21, 64, True), (4, 3001, 64, 32, 64, False), (1, 5000, 33, 47, 64, False), (2, 4000, 64, 16, 64, False)]
     for (B, N, L, hop, nfft, snip) in cases:
         x = (rng.standard_normal((B, N)) * 0.1).astype(dt)
         win = D.povey(L, dt) if L > 1 else np.ones(1, dt)

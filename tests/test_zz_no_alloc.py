@@ -51,6 +51,9 @@ def _both(O, B, N, L, stp, nfft, snip=False, mn0=False, amp=False, lg=False, see
     (512, 400, 160, (64, 48000), (3, 16000)),
     (4096, 4096, 1024, (4, 300000), (2, 20000)),
     (256, 200, 80, (16, 30000), (2, 5000)),
+    (128, 100, 40, (16, 30000), (2, 5000)),
+    (64, 64, 16, (16, 20000), (3, 700)),
+    (1024, 1024, 256, (8, 60000), (2, 5000)),
     (8, 8, 3, (4, 1000), (1, 100)),
 ])
 def test_noalloc_matches_batch_dev_twice(O, nfft, L, stp, big, small):

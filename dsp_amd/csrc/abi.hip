@@ -57,6 +57,10 @@ struct FltKey {
 struct FltFraming {
     long long ss0 = 0, rd_shift = 0;
     int stp = 1, tbl_reach = -1;
+    // two-launch form (FrameDesc::w_head ...): head frames by the table, the others as frames of the signal cut to n_tail
+    int w_head = 0, tail_stp = 0, tail_reach = -1;
+    long long n_tail = 0, tail_ss0 = 0;
+    size_t tail_off = 0;                      // ints from the start of tbl to the tail's table (0: none)
     std::shared_ptr<int> tbl;                 // empty: equally spaced frames
     std::shared_ptr<std::vector<int>> htbl;   // the table on the host (the streamed host path cuts it into ranges of frames)
 };
@@ -198,6 +202,8 @@ int flt_desc(const char *fn, int dev, FrameDesc &d, size_t B, size_t N, size_t l
     auto apply = [&](const FltFraming &f) {
         d.ss0 = f.ss0; d.stp = f.stp; d.rd_shift = f.rd_shift; d.tbl_reach = f.tbl_reach;
         hold = f.tbl; d.tbl = f.tbl.get();
+        d.w_head = f.w_head; d.tail_stp = f.tail_stp; d.tail_reach = f.tail_reach; d.n_tail = f.n_tail; d.tail_ss0 = f.tail_ss0;
+        d.tail_tbl = f.tail_off ? f.tbl.get() + f.tail_off : nullptr;
         tl_flt_htbl = f.htbl;
     };
     DevState &st = g_dev[dev];
@@ -235,11 +241,44 @@ int flt_desc(const char *fn, int dev, FrameDesc &d, size_t B, size_t N, size_t l
             reach = std::max(reach, (long long)tbl[2 * w3] - tbl[2 * w]);
         }
         f.tbl_reach = (reach >= 0 && reach <= (1 << 30)) ? (int)reach : -1;   // (each kernel family has its own bound on it)
+        // The reference's pointer walk (c/stft_flt.c:66-88) reads the frames that start inside the signal `shift` samples
+        // before their start, where shift is the start of the first of them.  With first frames that hang over the start
+        // of the signal the read shift differs between frames, which only the general kernels take.  But frame w >= w1 (the
+        // first that starts inside) is exactly the frame at start - shift of the signal cut to N - shift samples, read where
+        // it starts: the fast kernels transform those as a batch of their own and the w1 head frames go by the table.
+        std::vector<int> tail;
+        if (shift != 0 && left_overlap && reach < 0) {
+            size_t w1 = 0;
+            while (w1 < W && tbl[2 * w1] < 0) { ++w1; }
+            bool ordered = w1 < W;
+            for (size_t w = w1; ordered && w + 1 < W; ++w) { ordered = tbl[2 * (w + 1)] >= tbl[2 * w]; }
+            if (ordered) {
+                const size_t Wt = W - w1;
+                const long long t0 = (long long)tbl[2 * w1] - shift;
+                const long long thop = (Wt >= 2) ? (long long)tbl[2 * (w1 + 1)] - tbl[2 * w1] : 1;
+                bool tuni = thop >= 1;
+                long long treach = 0;
+                for (size_t w = w1; w < W; ++w) {
+                    if ((long long)tbl[2 * w] - tbl[2 * w1] != (long long)(w - w1) * thop) { tuni = false; }
+                    const size_t w3 = (w + 3 < W) ? w + 3 : W - 1;
+                    treach = std::max(treach, (long long)tbl[2 * w3] - tbl[2 * w]);
+                }
+                f.w_head = (int)w1; f.n_tail = (long long)N - shift; f.tail_ss0 = t0;
+                if (tuni) { f.tail_stp = (int)thop; }
+                else {
+                    f.tail_stp = 0; f.tail_reach = (treach <= (1 << 30)) ? (int)treach : -1;
+                    tail.resize(2 * Wt);
+                    for (size_t w = 0; w < Wt; ++w) { tail[2 * w] = tail[2 * w + 1] = (int)((long long)tbl[2 * (w1 + w)] - shift); }
+                    f.tail_off = tbl.size();
+                }
+            }
+        }
         // (first use of a framing: an allocation and a blocking copy; repeated calls find it in the cache)
         int *p = nullptr;
-        HIPCHK(fn, hipMalloc((void **)&p, tbl.size() * sizeof(int)));
+        HIPCHK(fn, hipMalloc((void **)&p, (tbl.size() + tail.size()) * sizeof(int)));
         f.tbl = std::shared_ptr<int>(p, [](int *q) { (void)hipFree(q); });
         HIPCHK(fn, hipMemcpy(p, tbl.data(), tbl.size() * sizeof(int), hipMemcpyHostToDevice));
+        if (!tail.empty()) { HIPCHK(fn, hipMemcpy(p + tbl.size(), tail.data(), tail.size() * sizeof(int), hipMemcpyHostToDevice)); }
         f.htbl = std::make_shared<std::vector<int>>(std::move(tbl));
     }
     apply(f);
@@ -285,6 +324,19 @@ int run_fused(const char *fn, int dev, T *Yd, const T *Xd, const T *wd, const Fr
               const T *tw_fixed = nullptr, unsigned *take = nullptr)
 {
     if (d.W == 0 || d.B == 0) { return 0; }
+    if (d.n_tail > 0) {
+        // two launches (FrameDesc::w_head): the head frames by the table, the others as frames of the cut signal
+        const size_t F = (size_t)d.nfft / 2 + 1;
+        FrameDesc h = d;
+        h.n_tail = 0; h.w_head = 0; h.tail_tbl = nullptr; h.Wy = d.wy();
+        FrameDesc t = h;
+        h.W = d.w_head;
+        t.W = d.W - d.w_head; t.N = d.n_tail; t.rd_shift = 0; t.ss0 = d.tail_ss0;
+        t.tbl = d.tail_stp > 0 ? nullptr : d.tail_tbl; t.tbl_reach = d.tail_reach; t.stp = d.tail_stp > 0 ? d.tail_stp : 1;
+        if (h.W > 0 && run_fused<T>(fn, dev, Yd, Xd, wd, h, s, tw_fixed, take)) { return 1; }
+        if (t.W > 0) { return run_fused<T>(fn, dev, Yd + (size_t)d.w_head * F, Xd, wd, t, s, tw_fixed, take); }
+        return 0;
+    }
     const size_t nfft = (size_t)d.nfft;
     const int fam = family_of<T>(nfft);
     const T *tw = tw_fixed;
@@ -514,6 +566,12 @@ int run_fused_host_streamed(const char *fn, int dev, T *Y, const T *X, const T *
             dc.B = (int)k.nb; dc.ldx = (long long)k.n_in; dc.W = (int)k.nw;
             dc.ss0 = d.ss0 + (long long)k.w0 * d.stp;
             if (d.tbl) { dc.tbl = d.tbl + 2 * k.w0; }
+            if (d.n_tail > 0) {                        // a range of frames of a two-launch framing: what is left of its head, and its tail
+                const long long skip = std::max(0ll, (long long)k.w0 - d.w_head);
+                dc.w_head = (int)std::min<long long>(std::max(0ll, (long long)d.w_head - (long long)k.w0), (long long)k.nw);
+                dc.tail_ss0 = d.tail_ss0 + skip * d.tail_stp;
+                if (d.tail_tbl) { dc.tail_tbl = d.tail_tbl + 2 * skip; }
+            }
             rc = run_fused<T>(fn, dev, (T *)st.dev_out[sl], (const T *)st.dev_in[sl] - k.lo, (const T *)dw, dc, st.st_k, nullptr, nullptr);
             HIPCHK(fn, hipEventRecord(st.ev_k[sl], st.st_k));
             HIPCHK(fn, hipStreamWaitEvent(st.st_out, st.ev_k[sl], 0));

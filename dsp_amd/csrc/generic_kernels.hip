@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void stft_pow2_kernel(T *__restrict__ Y, const
 
         // real-FFT split fused with power: with A = Z_k + conj Z_{M-k}, B = Z_k - conj Z_{M-k},
         // X_k = (A - i W^k B)/2 and X_{M-k} = conj((A + i W^k B)/2)
-        T *y = Y + (b * d.W + w) * (long long)F;
+        T *y = Y + (b * d.wy() + w) * (long long)F;
         for (int k = tid; k <= (M >> 1); k += 256) {
             const int km = (M - k) & (M - 1);
             const T zr = buf[2 * k], zi = buf[2 * k + 1], mr = buf[2 * km], mi = buf[2 * km + 1];
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void stft_direct_kernel(T *__restrict__ Y, con
             for (int l = tid; l < L; l += 256) { v[l] -= mean; }
         }
         __syncthreads();
-        T *y = Y + (b * d.W + w) * (long long)F;
+        T *y = Y + (b * d.wy() + w) * (long long)F;
         for (int f = tid; f < F; f += 256) {
             const int k2 = f + odd;
             int a1 = 0, a2 = 0;

@@ -30,6 +30,7 @@ struct R256Args {
     int W;                // frames per signal
     int stp;              // hop
     int ss0;              // start of frame 0
+    int Wy;               // frames per signal in the output array
     int rd_shift;         // edge == 1: samples are read at n - rd_shift
     int edge;             // 0 reflect, 1 zero
     Epilogue epi;
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__
     int b = sid / a.sps;
     int w = (sid - b * a.sps) * FPS;
     const float *xb = X + (long long)b * a.ldx;
-    float *yb = Y + (long long)b * a.W * ROWF;
+    float *yb = Y + (long long)b * a.Wy * ROWF;
 
     const unsigned cnt_addr = ring_lds_addr(ticket);
     unsigned drawn = 0;
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__
             const int nb = nsid / a.sps;
             nw = (nsid - nb * a.sps) * FPS;
             nxb = X + (long long)nb * a.ldx;
-            nyb = Y + (long long)nb * a.W * ROWF;
+            nyb = Y + (long long)nb * a.Wy * ROWF;
         }
     };
 
@@ -394,7 +395,7 @@ bool r256_supported(const FrameDesc &d)
     const bool placed = d.tbl ? (d.tbl_reach >= 0 && (long long)r256_reach_mult(d.nfft) * d.tbl_reach + d.nfft <= span)
                               : (d.stp >= 1 && (long long)(fps - 1) * d.stp + d.nfft <= span);
     return placed && d.L >= 1 && d.L <= d.nfft &&
-           d.N < (1ll << 31) - 4096 && (long long)d.W * (d.nfft / 2 + 1) < (1ll << 30) && (long long)d.B * d.W < (1ll << 30) &&
+           d.N < (1ll << 31) - 4096 && (long long)d.wy() * (d.nfft / 2 + 1) < (1ll << 30) && (long long)d.B * d.W < (1ll << 30) &&
            d.ss0 > -(1ll << 30) && d.ss0 < (1ll << 30) && d.rd_shift >= 0 && d.rd_shift < (1ll << 30);
 }
 
@@ -431,7 +432,7 @@ static hipError_t launch_r256_cl(float *Y, const float *X, const float *win, con
 {
     constexpr int FPS = 64 / CL, NFFT = 32 * CL, MAXS = r256_max_span(CL);
     R256Args a{};
-    a.ldx = d.ldx; a.N = (int)d.N; a.L = d.L; a.W = d.W; a.stp = d.stp; a.ss0 = (int)d.ss0;
+    a.ldx = d.ldx; a.N = (int)d.N; a.L = d.L; a.W = d.W; a.Wy = d.wy(); a.stp = d.stp; a.ss0 = (int)d.ss0;
     a.rd_shift = (int)d.rd_shift; a.edge = d.edge; a.epi = d.epi;
     a.sps = (d.W + FPS - 1) / FPS;
     a.steps = d.B * a.sps;
@@ -468,7 +469,7 @@ hipError_t launch_stft_r256(float *Y, const float *X, const float *win, const fl
 // The complex form: Y[b][w][nfft/2 + 1] interleaved (re, im) pairs times `scale`; equally spaced frames, no mean removal.
 bool r256_cplx_supported(const FrameDesc &d)
 {
-    return r256_supported(d) && d.tbl == nullptr && !d.mn0 && !d.epi.any() && (long long)d.W * (d.nfft + 2) < (1ll << 30);
+    return r256_supported(d) && d.tbl == nullptr && !d.mn0 && !d.epi.any() && (long long)d.wy() * (d.nfft + 2) < (1ll << 30);
 }
 
 hipError_t launch_stft_r256_cplx(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, double scale, hipStream_t s)

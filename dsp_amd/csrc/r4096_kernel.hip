@@ -40,6 +40,7 @@ struct R4096Args {
     long long rd_shift;
     const int *tbl;
     int L, W, stp, edge;
+    int Wy;               // frames per signal in the output array
     Epilogue epi;
     int frames;           // B * W
     int B;                // signals
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         Where q;
         const int b = f / a.W;
         const int w = f - b * a.W;
-        q.row = (long long)b * a.W + w;
+        q.row = (long long)b * a.Wy + w;
         q.xb = X + (long long)b * a.ldx;
         if (a.tbl) { q.ss = a.tbl[2 * w]; q.rdoff = q.ss - (long long)a.tbl[2 * w + 1]; }
         else { q.ss = a.ss0 + (long long)w * a.stp; q.rdoff = a.rd_shift; }
@@ -550,7 +551,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         R4096_STAMP(4);
 
         // ---------------- split + power + store: lane handles bins k = 4 lane + c + 256 m and 2048 - k ----------------
-        float *y = Y + (RUN ? (long long)run_b * a.W + run_w0 + tpos : cur.row) * ((R4096_HACK & 4) ? 2048 : (CPLX ? 2 * F : F));
+        float *y = Y + (RUN ? (long long)run_b * a.Wy + run_w0 + tpos : cur.row) * ((R4096_HACK & 4) ? 2048 : (CPLX ? 2 * F : F));
         const C2 *zk = ex + zpos(4 * lane);                                // Z[k] at zk[256 m + c]
         const C2 *zq0 = ex + zpos(M - 4 * lane) - 768;                     // Z[2048 - 4 lane - 256 m] at zq0[256 (3 - m)]
         const C2 *zq4 = ex + zpos(M - 4 - 4 * lane) - 768;                 // Z[2048 - 4 lane - 256 m - 4 + i] at zq4[256 (3 - m) + i]
@@ -707,7 +708,7 @@ extern "C" int dsp_debug_read_stamps4096(unsigned long long *dst, size_t n)
 
 bool r4096_supported(const FrameDesc &d)
 {
-    return d.nfft == 4096 && d.L >= 1 && d.L <= 4096 && (long long)d.B * d.W < (1ll << 31) - 4096;
+    return d.nfft == 4096 && d.L >= 1 && d.L <= 4096 && (long long)d.B * d.wy() < (1ll << 31) - 4096;
 }
 
 // Counters of the run form, one state for every instantiation: the set a launch uses, cleared in the
@@ -769,7 +770,7 @@ hipError_t launch_stft_r4096(float *Y, const float *X, const float *win, const f
 {
     R4096Args a{};
     a.ldx = d.ldx; a.N = d.N; a.ss0 = d.ss0; a.rd_shift = d.rd_shift; a.tbl = d.tbl;
-    a.L = d.L; a.W = d.W; a.stp = d.stp; a.edge = d.edge; a.epi = d.epi;
+    a.L = d.L; a.W = d.W; a.Wy = d.wy(); a.stp = d.stp; a.edge = d.edge; a.epi = d.epi;
     a.frames = d.B * d.W;
     a.B = d.B;
     const bool full = d.L == 4096, epi = d.epi.any();
@@ -796,14 +797,14 @@ hipError_t launch_stft_r4096(float *Y, const float *X, const float *win, const f
 // The complex form: Y[b][w][2049] interleaved (re, im) pairs times `scale`; equally spaced frames, no mean removal.
 bool r4096_cplx_supported(const FrameDesc &d)
 {
-    return r4096_supported(d) && d.tbl == nullptr && !d.mn0 && !d.epi.any() && (long long)d.B * d.W < (1ll << 30);
+    return r4096_supported(d) && d.tbl == nullptr && !d.mn0 && !d.epi.any() && (long long)d.B * d.wy() < (1ll << 30);
 }
 
 hipError_t launch_stft_r4096_cplx(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, double scale, hipStream_t s)
 {
     R4096Args a{};
     a.ldx = d.ldx; a.N = d.N; a.ss0 = d.ss0; a.rd_shift = d.rd_shift; a.tbl = nullptr;
-    a.L = d.L; a.W = d.W; a.stp = d.stp; a.edge = d.edge; a.epi = d.epi;
+    a.L = d.L; a.W = d.W; a.Wy = d.wy(); a.stp = d.stp; a.edge = d.edge; a.epi = d.epi;
     a.frames = d.B * d.W;
     a.B = d.B;
     a.cscale = (float)scale;

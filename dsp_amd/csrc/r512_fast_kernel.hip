@@ -39,6 +39,7 @@ struct R512FastArgs {
     int steps;            // B * sps
     const int *tbl;       // table form: start of frame w at tbl[2 w] (frames need not be equally spaced)
     int all16;            // every step has 4 frames and its block of rows is 16-byte aligned
+    int Wy;               // frames per signal in the output array
     double cscale;        // complex form: factor on every output value (1, or 1 / sqrt(2 nfft))
 };
 
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
     int b = sid / a.sps;
     int w = (sid - b * a.sps) * 4;
     const T *xb = X + (long long)b * a.ldx;
-    T *yb = Y + (long long)b * a.W * ROWF;
+    T *yb = Y + (long long)b * a.Wy * ROWF;
 
     // the wave's next step, from its latest draw
     const unsigned cnt_addr = ring_lds_addr(ticket);
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
             const int nb = nsid / a.sps;
             nw = (nsid - nb * a.sps) * 4;
             nxb = X + (long long)nb * a.ldx;
-            nyb = Y + (long long)nb * a.W * ROWF;
+            nyb = Y + (long long)nb * a.Wy * ROWF;
         }
     };
 
@@ -637,7 +638,7 @@ bool r512_fast_supported(const FrameDesc &d)
 {
     const bool placed = d.tbl ? (d.tbl_reach >= 0 && d.tbl_reach + 512 <= 2048) : (3ll * d.stp + 512 <= 2048);
     return placed && d.nfft == 512 && d.L >= 1 && d.L <= 512 &&
-           d.N < (1ll << 31) - 4096 && (long long)d.W * 257 < (1ll << 30) && (long long)d.B * ((d.W + 3) / 4) < (1ll << 30) && d.ss0 > -(1ll << 30) && d.ss0 < (1ll << 30) &&
+           d.N < (1ll << 31) - 4096 && (long long)d.wy() * 257 < (1ll << 30) && (long long)d.B * ((d.W + 3) / 4) < (1ll << 30) && d.ss0 > -(1ll << 30) && d.ss0 < (1ll << 30) &&
            d.rd_shift >= 0 && d.rd_shift < (1ll << 30);
 }
 
@@ -679,7 +680,7 @@ hipError_t launch_stft_r512_fast(T *Y, const T *X, const T *win, const T *tw, co
     for (long long b0 = 0; b0 < d.B; b0 += (long long)nb) {
         FrameDesc part = d;
         part.B = (int)(((long long)nb < d.B - b0) ? (long long)nb : d.B - b0);
-        if (hipError_t e = launch_stft_r512_fast_one<T>(Y + (size_t)b0 * d.W * 257, X + (size_t)b0 * d.ldx, win, tw, part, s); e != hipSuccess) { return e; }
+        if (hipError_t e = launch_stft_r512_fast_one<T>(Y + (size_t)b0 * d.wy() * 257, X + (size_t)b0 * d.ldx, win, tw, part, s); e != hipSuccess) { return e; }
     }
     return hipSuccess;
 }
@@ -694,7 +695,8 @@ static hipError_t launch_stft_r512_fast_one(T *Y, const T *X, const T *win, cons
     a.steps = d.B * a.sps;
     a.tbl = d.tbl;
     if (d.tbl) { a.stp = d.tbl_reach; a.ss0 = 0; a.rd_shift = 0; }
-    a.all16 = (d.W % 4 == 0) && (reinterpret_cast<uintptr_t>(Y) % 16 == 0);
+    a.all16 = (d.W % 4 == 0) && (d.wy() % 4 == 0) && (reinterpret_cast<uintptr_t>(Y) % 16 == 0);
+    a.Wy = d.wy();
     const bool epi = d.epi.any();
     // float, equally spaced frames: spans by LDS-DMA (the double kernel's exchange tiles leave no LDS for span slots)
     constexpr bool RING = sizeof(T) == 4 && R512F_RING_F32;
@@ -753,7 +755,7 @@ static hipError_t launch_stft_r512_fast_one(T *Y, const T *X, const T *win, cons
 // The complex form: Y[b][w][257] interleaved (re, im) pairs times `scale`; equally spaced frames, no mean removal.
 bool r512_fast_cplx_supported(const FrameDesc &d)
 {
-    return r512_fast_supported(d) && d.tbl == nullptr && !d.mn0 && !d.epi.any() && (long long)d.W * 514 < (1ll << 30);
+    return r512_fast_supported(d) && d.tbl == nullptr && !d.mn0 && !d.epi.any() && (long long)d.wy() * 514 < (1ll << 30);
 }
 
 template <typename T>
@@ -769,7 +771,8 @@ hipError_t launch_stft_r512_fast_cplx(T *Y, const T *X, const T *win, const T *t
     a.steps = d.B * a.sps;
     a.tbl = nullptr;
     a.cscale = scale;
-    a.all16 = (d.W % 4 == 0) && (reinterpret_cast<uintptr_t>(Y) % 16 == 0);
+    a.all16 = (d.W % 4 == 0) && (d.wy() % 4 == 0) && (reinterpret_cast<uintptr_t>(Y) % 16 == 0);
+    a.Wy = d.wy();
     constexpr bool RING = sizeof(T) == 4 && R512F_RING_F32;
     const bool wide = 3 * d.stp + 512 > 1024 || (d.stp & 1);
     const bool nr13 = d.L > 384 && d.L <= 416;

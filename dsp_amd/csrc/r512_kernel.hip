@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void stft_r512_kernel(T *__restrict__ Y, const
             for (int g = 0; g < 4; ++g) {
                 if (w + g >= wend) { break; }
                 const T2 *zf = ex + g * R512_EXF;
-                T *y = Y + ((long long)b * d.W + (w + g)) * F;
+                T *y = Y + ((long long)b * d.wy() + (w + g)) * F;
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     const int k = lane + 64 * m;

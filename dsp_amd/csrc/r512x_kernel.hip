@@ -32,6 +32,7 @@ struct R512XArgs {
     int N;                // samples per signal
     int L;                // window length
     int W;                // frames per signal
+    int Wy;               // frames per signal in the output array
     int stp;              // hop
     int ss0;              // start of frame 0
     int rd_shift;         // edge == 1: samples are read at n - rd_shift
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
     int b = sid / a.sps;
     int w = (sid - b * a.sps) * FPS;
     const float *xb = X + (long long)b * a.ldx;
-    float *yb = Y + (long long)b * a.W * ROWF;
+    float *yb = Y + (long long)b * a.Wy * ROWF;
 
     const unsigned cnt_addr = ring_lds_addr(ticket);
     unsigned drawn = 0;
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
             const int nb = nsid / a.sps;
             nw = (nsid - nb * a.sps) * FPS;
             nxb = X + (long long)nb * a.ldx;
-            nyb = Y + (long long)nb * a.W * ROWF;
+            nyb = Y + (long long)nb * a.Wy * ROWF;
         }
     };
 
@@ -485,7 +486,7 @@ bool r512x_supported(const FrameDesc &d)
     const bool placed = d.tbl ? (d.tbl_reach >= 0 && (fps == 1 || d.tbl_reach + d.nfft <= 2048))
                               : (d.stp >= 1 && (long long)(fps - 1) * d.stp + d.nfft <= 2048);
     return placed && d.L >= 1 && d.L <= d.nfft &&
-           d.N < (1ll << 31) - 4096 && (long long)d.W * (d.nfft / 2 + 1) < (1ll << 30) && (long long)d.B * d.W < (1ll << 30) &&
+           d.N < (1ll << 31) - 4096 && (long long)d.wy() * (d.nfft / 2 + 1) < (1ll << 30) && (long long)d.B * d.W < (1ll << 30) &&
            d.ss0 > -(1ll << 30) && d.ss0 < (1ll << 30) && d.rd_shift >= 0 && d.rd_shift < (1ll << 30);
 }
 
@@ -525,7 +526,7 @@ hipError_t launch_stft_r512x(float *Y, const float *X, const float *win, const f
 {
     const int Q = d.nfft / 512, fps = 4 / Q;
     R512XArgs a{};
-    a.ldx = d.ldx; a.N = (int)d.N; a.L = d.L; a.W = d.W; a.stp = d.stp; a.ss0 = (int)d.ss0;
+    a.ldx = d.ldx; a.N = (int)d.N; a.L = d.L; a.W = d.W; a.Wy = d.wy(); a.stp = d.stp; a.ss0 = (int)d.ss0;
     a.rd_shift = (int)d.rd_shift; a.edge = d.edge; a.epi = d.epi;
     a.sps = (d.W + fps - 1) / fps;
     a.steps = d.B * a.sps;
@@ -540,7 +541,7 @@ hipError_t launch_stft_r512x(float *Y, const float *X, const float *win, const f
 // The complex form: Y[b][w][nfft/2+1] interleaved (re, im) pairs times `scale`; equally spaced frames, no mean removal.
 bool r512x_cplx_supported(const FrameDesc &d)
 {
-    return r512x_supported(d) && d.tbl == nullptr && !d.mn0 && !d.epi.any() && (long long)d.W * (d.nfft + 2) < (1ll << 30);
+    return r512x_supported(d) && d.tbl == nullptr && !d.mn0 && !d.epi.any() && (long long)d.wy() * (d.nfft + 2) < (1ll << 30);
 }
 
 template <int Q, int SPAN, bool ALN>
@@ -558,7 +559,7 @@ hipError_t launch_stft_r512x_cplx(float *Y, const float *X, const float *win, co
 {
     const int Q = d.nfft / 512, fps = 4 / Q;
     R512XArgs a{};
-    a.ldx = d.ldx; a.N = (int)d.N; a.L = d.L; a.W = d.W; a.stp = d.stp; a.ss0 = (int)d.ss0;
+    a.ldx = d.ldx; a.N = (int)d.N; a.L = d.L; a.W = d.W; a.Wy = d.wy(); a.stp = d.stp; a.ss0 = (int)d.ss0;
     a.rd_shift = (int)d.rd_shift; a.edge = d.edge; a.epi = d.epi;
     a.sps = (d.W + fps - 1) / fps;
     a.steps = d.B * a.sps;

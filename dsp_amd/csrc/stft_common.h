@@ -37,6 +37,17 @@ struct FrameDesc {
     int mn0;
     Epilogue epi;
     int B;               // signals
+    int Wy;              // frames per signal in the OUTPUT array: the rows of signal b start at row b * Wy (0: W).  A launch
+                         // over a range of a batch's frames writes W frames per signal into rows that are Wy apart.
+    // frames per signal of the output array
+    __host__ __device__ int wy() const { return Wy ? Wy : W; }
+    // stft_flt framings whose first frames hang over the start of the signal while the later ones are read with a shift
+    // (reference c/stft_flt.c:66-88) go in two launches: frames [0, w_head) by the table, frames [w_head, W) as frames of
+    // the signal cut to n_tail samples, read where they start, at tail_stp-spaced starts from tail_ss0 (tail_stp > 0) or at
+    // the starts in tail_tbl (reach tail_reach).  w_head == 0: one launch.
+    int w_head, tail_stp, tail_reach;
+    long long n_tail, tail_ss0;
+    const int *tail_tbl;
 };
 
 template <typename T>

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(64 * wave_wpw(NFFT / 2, (int)sizeof(T)), 2) void st
         frame_origin(d, w, q.ss, q.rdoff);
         if (!d.edge) { q.rdoff = 0; }
         q.xb = X + b * d.ldx;
-        q.row = b * d.W + w;
+        q.row = b * d.wy() + w;
         q.inside = q.ss >= 0 && q.ss + L <= d.N && q.ss >= q.rdoff;
         return q;
     };

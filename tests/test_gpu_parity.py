@@ -1232,6 +1232,37 @@ def test_host_entry_points_from_several_threads(O, D):
     check_spec(O, alone["r4096"][3, :Yref.shape[0] - 3].cpu().numpy(), Yref[:-3])
 
 
+def test_stft_flt_reference_framing_head_and_tail(O, D):
+    """stft_flt in the reference's framing (c/stft_flt.c:66-88) with first frames that hang over the start of the signal:
+    the frames that start inside the signal are read `shift` samples early, the ones before them where they start.  The
+    library transforms such a call in two launches (head frames by the table; the others as frames of the signal cut to
+    N - shift samples, on the fast kernels): batches of several signals (the tail's rows of signal b start W rows after
+    those of signal b - 1, not W - head), every kernel family, whole and fractional hops, a head longer than one step, a
+    frame count that ends inside and beyond the signal, the flags; against the oracle's restatement of the reference's
+    walk, signal by signal."""
+    import torch
+    rng = np.random.default_rng(123)
+    cases = [(np.float32, 512, 400, 0.0, 160.0, 0), (np.float32, 512, 400, 37.0, 160.5, 1), (np.float64, 512, 400, 0.0, 160.0, 2),
+             (np.float64, 512, 400, 150.0, 100.25, 0), (np.float32, 512, 512, -300.0, 64.0, 3), (np.float32, 256, 200, 0.0, 80.0, 0),
+             (np.float32, 128, 100, 10.0, 40.5, 1), (np.float32, 64, 64, 0.0, 16.0, 0), (np.float32, 1024, 1024, 100.0, 256.0, 2),
+             (np.float32, 2048, 2048, 0.0, 512.5, 0), (np.float32, 4096, 4096, 1000.0, 1024.0, 0), (np.float64, 1024, 800, 0.0, 200.0, 1),
+             (np.float32, 100, 100, 0.0, 25.0, 3), (np.float32, 512, 400, 0.0, 3.0, 0)]
+    flag_sets = [(0, 0, 0), (1, 0, 0), (0, 1, 1), (1, 1, 0)]
+    for (dt, nfft, L, c0, stp, fl) in cases:
+        B = 3
+        for N in (60000, 9000):
+            for W in (int((N - 1 - c0) // stp) - 1, min(N, int((N + 3 * L - c0) // stp))):
+                x = (rng.standard_normal((B, N)) * 0.1 + 0.05).astype(dt)
+                win = D.povey(L, dt)
+                mn0, amp, lg = flag_sets[fl]
+                Y = D.stft_flt_dev(torch.from_numpy(x).cuda(), torch.from_numpy(win).cuda(), W, c0, stp, bool(mn0), bool(amp), bool(lg), nfft=nfft)
+                Y = Y.cpu().numpy()
+                for b in range(B):
+                    rc, Yref = O.stft_flt(x[b].astype(np.float64), win.astype(np.float64), W, c0, stp, nfft, mn0, amp, lg, intended=False, exact=False)
+                    assert rc == 0
+                    check_spec(O, Y[b], Yref.astype(dt), amp, lg)
+
+
 def test_host_long_signal_streamed_by_frames(O, D):
     """One long signal through the reference's own host-pointer entry points (stft_s/_d, stft_flt_s/_d: configurations
     3 and 4 of the benchmark list are 64 / 128 such calls): from 64 MB of input + output on the call goes through in
@@ -1271,6 +1302,16 @@ def test_host_long_signal_streamed_by_frames(O, D):
         Zh = D.stft_flt(x, win, W, 200.0, 160.5, lg=True)
         Zd = D.stft_flt_dev(xd[None, :], wd, W, 200.0, 160.5, lg=True)[0].cpu().numpy()
         assert np.array_equal(Zh, Zd)
+        # reference framing with first frames that hang over the start of the signal (two launches per range of frames:
+        # what is left of the head by the table, the rest as frames of the cut signal), whole and fractional hop
+        for (c0, stp) in ((0.0, 160.0), (37.0, 160.5)):
+            W = int((N - 1 - c0) // stp) - 2
+            Zh = D.stft_flt(x, win, W, c0, stp)
+            Zd = D.stft_flt_dev(xd[None, :], wd, W, c0, stp)[0].cpu().numpy()
+            assert np.array_equal(Zh, Zd)
+            rc, Zref = O.stft_flt(x[:40000].astype(np.float64), win.astype(np.float64), 200, c0, stp, 512, 0, 0, 0, intended=False, exact=False)
+            assert rc == 0
+            check_spec(O, Zh[:200], Zref.astype(dt))
         del Yh, Yd, Zh, Zd
     # other kernel families: nfft 1024 (hop 256), nfft 4096 (hop 1024: run form inside the ranges), odd hop
     x = (rng.standard_normal(40_000_000) * 0.1).astype(np.float32)

@@ -212,10 +212,62 @@ __global__ __launch_bounds__(256) void gather_signals_kernel(T *__restrict__ Y, 
     }
 }
 
+// The same gather for interleaved channels (ldx == 1: the B signals of a sample are adjacent) with 16-byte accesses on both
+// sides: a workgroup takes 64 channels x TN samples (1 KiB of output per channel), reads vectors of 16 / sizeof(T) adjacent
+// channels of one sample (a wave: 4 samples x 64 channels, 1 KiB where incx == 64), writes them to the LDS tile element by
+// element (row pitch TN + 1: conflict-free), reads the tile along the samples and stores vectors of consecutive samples, a
+// wave a whole KiB of one channel.  All of a thread's loads are issued before the first is used.
+template <typename T>
+__global__ __launch_bounds__(256) void gather_interleaved_kernel(T *__restrict__ Y, const T *__restrict__ X, const size_t N, const size_t B,
+                                                               const size_t incx, const size_t tiles_n, const size_t tiles)
+{
+    constexpr int VEC = 16 / (int)sizeof(T), TN = 1024 / (int)sizeof(T), CV = 64 / VEC, NPP = 256 / CV, PASSES = TN / NPP;
+    typedef T vecT __attribute__((ext_vector_type(VEC)));
+    __shared__ T tile[64][TN + 1];
+    const int tid = threadIdx.x;
+    const int cv = tid % CV, nl = tid / CV;                // load side: channel vector, sample within a pass
+    const int q = tid % (TN / VEC), cl = tid / (TN / VEC); // store side: sample vector, channel within a pass
+    constexpr int CPP = 256 / (TN / VEC), SPASSES = 64 / CPP;
+    for (size_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const size_t b0 = (t / tiles_n) * 64, n0 = (t % tiles_n) * TN;
+        vecT v[PASSES];
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+            const size_t n = n0 + nl + NPP * i, b = b0 + cv * VEC;
+            v[i] = vecT(0);
+            if (n < N && b < B) { v[i] = *reinterpret_cast<const vecT *>(X + n * incx + b); }
+        }
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) { tile[cv * VEC + k][nl + NPP * i] = v[i][k]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SPASSES; ++j) {
+            const int ch = cl + CPP * j;
+            const size_t b = b0 + ch, n = n0 + (size_t)q * VEC;
+            vecT o;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) { o[k] = tile[ch][q * VEC + k]; }
+            if (b < B && n < N) { *reinterpret_cast<vecT *>(Y + b * N + n) = o; }
+        }
+        __syncthreads();
+    }
+}
+
 template <typename T>
 hipError_t launch_gather_signals(T *Y, const T *X, size_t N, size_t B, size_t ldx, size_t incx, hipStream_t s)
 {
     if (N == 0 || B == 0) { return hipSuccess; }
+    constexpr size_t VEC = 16 / sizeof(T), TN = 1024 / sizeof(T);
+    if (ldx == 1 && incx % VEC == 0 && B % VEC == 0 && N % VEC == 0 && reinterpret_cast<uintptr_t>(X) % 16 == 0 &&
+        reinterpret_cast<uintptr_t>(Y) % 16 == 0) {
+        const size_t tiles_n = (N + TN - 1) / TN, tiles = tiles_n * ((B + 63) / 64);
+        const size_t grid = tiles < 256 * 2 ? tiles : 256 * 2;
+        hipLaunchKernelGGL(gather_interleaved_kernel<T>, dim3((unsigned)grid), dim3(256), 0, s, Y, X, N, B, incx, tiles_n, tiles);
+        return hipGetLastError();
+    }
     const size_t tiles_n = (N + 63) / 64, tiles = tiles_n * ((B + 63) / 64);
     const size_t grid = tiles < 256 * 16 ? tiles : 256 * 16;
     hipLaunchKernelGGL(gather_signals_kernel<T>, dim3((unsigned)grid), dim3(256), 0, s, Y, X, N, B, ldx, incx, tiles_n, tiles);

@@ -606,7 +606,9 @@ def test_interleaved_channels_equal_channels_alone(O, D, dt):
     tdt = torch.float32 if dt == np.float32 else torch.float64
     g = torch.Generator(device="cuda").manual_seed(17)
     win = torch.from_numpy(D.povey(400, dt)).cuda()
-    for (N, Cc) in [(48000, 64), (20011, 7), (9000, 130)]:
+    # (64 / 8 / 68 / 132 channels with a sample count that is a multiple of 4: the gather with 16-byte accesses, whole
+    # and partial tiles; the others: the element-wise gather)
+    for (N, Cc) in [(48000, 64), (20011, 7), (9000, 130), (16384, 8), (5000, 68), (3332, 132)]:
         t = torch.randn((N, Cc), generator=g, device="cuda", dtype=tdt)           # [N][C]
         x = t.T                                                                    # [C][N] view, stride (1, C)
         dense = x.contiguous()
@@ -618,6 +620,8 @@ def test_interleaved_channels_equal_channels_alone(O, D, dt):
         sub = D.stft_dev(x[1:5], win, 160)                                         # a block of the channels
         torch.cuda.synchronize()
         assert torch.equal(Y, Yd) and torch.equal(Z, Zd) and torch.equal(sub, Yd[1:5])
+        if Cc >= 8:
+            assert torch.equal(D.stft_dev(x[4:8], win, 160), Yd[4:8])              # a block that starts on a 16-byte boundary
         c = Cc - 1
         rc, Yref = O.stft(dense[c].cpu().numpy(), win.cpu().numpy(), 160, 512, exact=False)
         check_spec(O, Y[c].cpu().numpy(), Yref)

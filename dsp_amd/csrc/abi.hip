@@ -308,7 +308,7 @@ int family_of(size_t nfft)
     if (nfft == 512 && !tl_force_generic) { return 3; }
     if (nfft == 4096 && sizeof(T) == 4 && !tl_force_generic) { return 4; }
     if ((nfft == 1024 || nfft == 2048) && sizeof(T) == 4 && !tl_force_generic) { return 6; }
-    if ((nfft == 256 || nfft == 128 || nfft == 64) && sizeof(T) == 4 && !tl_force_generic) { return 7; }
+    if ((nfft == 256 || nfft == 128 || nfft == 64) && !tl_force_generic) { return 7; }
     if (!tl_force_generic && nfft <= (1u << 20)) {
         FrameDesc probe{};
         probe.nfft = (int)nfft; probe.L = 1;
@@ -363,11 +363,9 @@ int run_fused(const char *fn, int dev, T *Yd, const T *Xd, const T *wd, const Fr
             return 0;
         }
     }
-    if constexpr (sizeof(T) == 4) {
-        if (fam == 7 && r256_supported(d)) {
-            HIPCHK(fn, launch_stft_r256(Yd, Xd, wd, tw, d, s));
-            return 0;
-        }
+    if (fam == 7 && r256_supported(d)) {
+        HIPCHK(fn, launch_stft_r256(Yd, Xd, wd, tw, d, s));
+        return 0;
     }
     if (fam >= 5 && wave_fft_supported<T>(d)) {
         HIPCHK(fn, launch_stft_wave<T>(Yd, Xd, wd, tw, d, s));

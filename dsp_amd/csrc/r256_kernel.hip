@@ -1,4 +1,4 @@
-// Fused STFT kernel for nfft = 256, 128 and 64, float32 (gfx950).
+// Fused STFT kernel for nfft = 256, 128 and 64, float32 and float64 (gfx950).
 //
 // The kernel is written for CL lanes per frame, nfft = 32 CL: CL = 8 (nfft 256, described below), 4 (nfft 128: 64 complex
 // points as 16 x 4 on 4 lanes, 16 frames per wave and step, pass 2 four 4-point FFTs per lane) and 2 (nfft 64: 16 x 2 on
@@ -17,6 +17,9 @@
 // step (7 hop + 256 samples at most 2048) comes by LDS-DMA into a slot of the wave's own; rows are staged
 // through LDS in output order, shifted so that the 16-byte boundaries of the output fall on 16-byte boundaries of
 // the LDS, and leave as 16-byte non-temporal stores: six store instructions per step whatever the alignment.
+// float64: the same kernel with 4 waves per workgroup (a wave's tile and span slot take twice the bytes; one wave per
+// SIMD also has the registers for the 16 complex values, the twiddles and the window taps in double) and rows stored
+// element-wise, 17 store instructions per step.
 #include "stft_common.h"
 #include "fft16.h"
 #include "span_ring.h"
@@ -38,7 +41,7 @@ struct R256Args {
     int steps;            // B * sps
     const int *tbl;       // table form: start of frame w at tbl[2 w] (frames need not be equally spaced); else nullptr
     int reach;            // table form: bound on the distance between the starts of the first and last frame of a step
-    float cscale;         // complex form: factor on every output value
+    double cscale;        // complex form: factor on every output value
 };
 
 // Exchange tile of a wave: per frame 16 rows k1 of CL values at row pitch CL + 1; the frame pitch (complex slots) makes
@@ -46,7 +49,7 @@ struct R256Args {
 // fall on 32 different 8-byte banks over a half-wave.
 __host__ __device__ constexpr int r256_fp(int CL) { return CL == 8 ? 152 : CL == 4 ? 84 : 50; }
 __host__ __device__ constexpr int r256_tile(int CL) { return (64 / CL) * r256_fp(CL) * 2; }   // floats: exchange tile / row staging
-constexpr int R256_WAVES = 8;
+template <typename T> __host__ __device__ constexpr int r256_waves() { return sizeof(T) == 4 ? 8 : 4; }   // per workgroup
 
 #ifndef R256_MINIMAL
 #define R256_MINIMAL 0          // diagnostic builds: 1 = only the plain instantiations
@@ -69,19 +72,26 @@ template <int CL> __device__ __forceinline__ float r256_grp_neg(float v)
     else { return v; }
 }
 
+template <int CL> __device__ __forceinline__ double r256_grp_neg(double v)   // the two halves of a double move separately
+{
+    const float lo = r256_grp_neg<CL>(__int_as_float(__double2loint(v))), hi = r256_grp_neg<CL>(__int_as_float(__double2hiint(v)));
+    return __hiloint2double(__float_as_int(hi), __float_as_int(lo));
+}
+
 // forward 8-point DFT; X[k] is left in a[slot8(k)]
 __host__ __device__ constexpr int slot8(int k) { return k < 4 ? 2 * k : 2 * (k - 4) + 1; }
-__device__ __forceinline__ void dft8c(cx<float> (&a)[8])
+template <typename T>
+__device__ __forceinline__ void dft8c(cx<T> (&a)[8])
 {
-    constexpr float R2 = 0.70710678118654752440084436210484904f;
-    dft4c<float>(a[0], a[2], a[4], a[6]);            // E[k] in a[2 k]
-    dft4c<float>(a[1], a[3], a[5], a[7]);            // O[k] in a[2 k + 1]
-    a[3] = cx_mul<float>(a[3], R2, -R2);             // W8^1
-    a[5] = cx_swap(a[5]) * cx<float>{1.f, -1.f};     // W8^2 = -i
-    a[7] = cx_mul<float>(a[7], -R2, -R2);            // W8^3
+    constexpr T R2 = T(0.70710678118654752440084436210484904L);
+    dft4c<T>(a[0], a[2], a[4], a[6]);                // E[k] in a[2 k]
+    dft4c<T>(a[1], a[3], a[5], a[7]);                // O[k] in a[2 k + 1]
+    a[3] = cx_mul<T>(a[3], R2, -R2);                 // W8^1
+    a[5] = cx_swap(a[5]) * cx<T>{T(1), T(-1)};       // W8^2 = -i
+    a[7] = cx_mul<T>(a[7], -R2, -R2);                // W8^3
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const cx<float> e = a[2 * k], o = a[2 * k + 1];
+        const cx<T> e = a[2 * k], o = a[2 * k + 1];
         a[2 * k] = e + o;
         a[2 * k + 1] = e - o;
     }
@@ -89,29 +99,32 @@ __device__ __forceinline__ void dft8c(cx<float> (&a)[8])
 
 // forward CL-point DFT of a row of pass 2; X[k] is left in a[r256_slot<CL>(k)]
 template <int CL> __host__ __device__ constexpr int r256_slot(int k) { return CL == 8 ? slot8(k) : k; }
-template <int CL> __device__ __forceinline__ void r256_dft_row(cx<float> (&a)[CL])
+template <typename T, int CL> __device__ __forceinline__ void r256_dft_row(cx<T> (&a)[CL])
 {
-    if constexpr (CL == 8) { dft8c(a); }
-    else if constexpr (CL == 4) { dft4c<float>(a[0], a[1], a[2], a[3]); }
-    else { const cx<float> t = a[0]; a[0] = t + a[1]; a[1] = t - a[1]; }
+    if constexpr (CL == 8) { dft8c<T>(a); }
+    else if constexpr (CL == 4) { dft4c<T>(a[0], a[1], a[2], a[3]); }
+    else { const cx<T> t = a[0]; a[0] = t + a[1]; a[1] = t - a[1]; }
 }
 
 // CPLX: the rows are the complex spectra (nfft/2 + 1 interleaved (re, im) pairs per frame, the imaginary parts of the first and
 // last zero: window_univar followed by fft_fftw_r2hc, reference c/window_univar.c:41-89, c/fft.fftw.r2hc.c:69-78) instead of
 // their powers.
-template <int CL, int NR, bool MN0, bool EPI, int SPAN, bool ALN, bool CPLX = false>
-__global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__restrict__ Y, const float *__restrict__ X,
-                                                                       const float *__restrict__ win, const float *__restrict__ tw,
-                                                                       const R256Args a)
+template <typename T, int CL, int NR, bool MN0, bool EPI, int SPAN, bool ALN, bool CPLX = false>
+__global__ __launch_bounds__(64 * r256_waves<T>(), sizeof(T) == 4 ? 2 : 1) void stft_r256_kernel(T *__restrict__ Y, const T *__restrict__ X,
+                                                                                             const T *__restrict__ win, const T *__restrict__ tw,
+                                                                                             const R256Args a)
 {
-    using C = cx<float>;
-    typedef float f2e __attribute__((ext_vector_type(2), aligned(4)));
-    constexpr int M = 16 * CL, F = M + 1, FPS = 64 / CL, RW = 16 / CL, NWV = R256_WAVES, NV = SPAN / 256;
+    using C = cx<T>;
+    typedef T pair_u __attribute__((ext_vector_type(2), aligned(sizeof(T))));        // a pair of samples at sample alignment
+    typedef T pair_a __attribute__((ext_vector_type(2), aligned(2 * sizeof(T))));    // ... at its own alignment
+    constexpr bool F32 = sizeof(T) == 4;
+    constexpr int M = 16 * CL, F = M + 1, FPS = 64 / CL, RW = 16 / CL, NWV = r256_waves<T>(), NV = SPAN * (int)sizeof(T) / 1024;
     constexpr int RP = CL + 1, FP = r256_fp(CL), TILE = r256_tile(CL);
     constexpr int WAVE_LDS = TILE + SPAN;
     static_assert(CL == 8 || CL == 4 || CL == 2, "8, 4 or 2 lanes per frame");
-    constexpr int ROWF = CPLX ? 2 * F : F;                 // floats of an output row
-    constexpr int NVI = (FPS * ROWF + 255) / 256;          // whole-vector wave stores of a step's block of rows
+    constexpr int ROWF = CPLX ? 2 * F : F;                 // values of an output row
+    constexpr int NVI = (FPS * ROWF + 255) / 256;          // float32: whole-vector wave stores of a step's block of rows
+    constexpr int NSTORE = F32 ? NVI + 1 : (FPS * ROWF + 63) / 64;   // store instructions per step
     static_assert(FPS * ROWF + 3 <= TILE && 16 * RP <= FP, "row staging and a frame's rows fit the tile");
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -119,26 +132,26 @@ __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__
     const int f = lane / CL, j = lane % CL;
     const int L = a.L;
 
-    float *xs = reinterpret_cast<float *>(smem_raw) + wv * WAVE_LDS;   // exchange tile, then row staging
-    float2 *ex = reinterpret_cast<float2 *>(xs);
-    float *slot = xs + TILE;                                      // the span
-    float *dummy = reinterpret_cast<float *>(smem_raw) + NWV * WAVE_LDS;   // 1 KiB that placeholder LDS-DMA loads write
-    unsigned *ticket = reinterpret_cast<unsigned *>(dummy + 256);
+    T *xs = reinterpret_cast<T *>(smem_raw) + wv * WAVE_LDS;      // exchange tile, then row staging
+    pair_a *ex = reinterpret_cast<pair_a *>(xs);
+    T *slot = xs + TILE;                                          // the span
+    unsigned char *dummy = smem_raw + (size_t)NWV * WAVE_LDS * sizeof(T);   // 1 KiB that placeholder LDS-DMA loads write
+    unsigned *ticket = reinterpret_cast<unsigned *>(dummy + 1024);
 
     // ---- per-lane constants ----
     C twd[16];                                             // W_M^(j k1) = W_nfft^(2 j k1), 2 j k1 < nfft
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) {
         int idx = 2 * j * k1;
-        float sg = 1.0f;
-        if (idx >= M) { idx -= M; sg = -1.0f; }
+        T sg = T(1);
+        if (idx >= M) { idx -= M; sg = T(-1); }
         twd[k1] = C{sg * tw[2 * idx], sg * tw[2 * idx + 1]};
     }
     C hw[NR];                                              // halved window taps of the lane's column
 #pragma unroll
     for (int n1 = 0; n1 < NR; ++n1) {
         const int l = 2 * CL * n1 + 2 * j;
-        hw[n1] = C{(l < L) ? 0.5f * win[l] : 0.f, (l + 1 < L) ? 0.5f * win[l + 1] : 0.f};
+        hw[n1] = C{(l < L) ? T(0.5) * win[l] : T(0), (l + 1 < L) ? T(0.5) * win[l + 1] : T(0)};
     }
     C ow[RW][CL / 2];                                      // -i W_nfft^K for K = j + CL r + 16 k2, k2 < CL/2
 #pragma unroll
@@ -154,7 +167,7 @@ __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__
 
     const int reach = a.tbl ? a.reach : (FPS - 1) * a.stp;
     const int need = reach + min(L, 2 * CL * NR);             // samples of a span that pass 1 uses
-    const float *xrow = slot + f * a.stp + 2 * j;
+    const T *xrow = slot + f * a.stp + 2 * j;
     // Start of the span of the step at frame w_ (wave-uniform).  Table form: the starts of the step's frames by
     // scalar loads (a vector load would put the compiler's own wait for ALL outstanding memory operations, the row
     // stores included, in front of the span fetch), and xrow for that step: called when pass 1 is done with the last one.
@@ -175,9 +188,9 @@ __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__
 
     // ---- fetch of one span into the slot: NV LDS-DMA loads whatever the case (the counted wait relies on
     // that); a span that crosses an edge of its signal is gathered sample by sample and NV placeholder loads follow
-    auto load_span = [&](const float *xb, const int s0) {
-        ring_load_span<NV>(slot, dummy, tw, xb, s0, need, a.N, a.edge, a.rd_shift, lane,
-                           [&](const float *sig, const int first, const int i) {
+    auto load_span = [&](const T *xb, const int s0) {
+        ring_load_span<NV>(slot, reinterpret_cast<T *>(dummy), tw, xb, s0, need, a.N, a.edge, a.rd_shift, lane,
+                           [&](const T *sig, const int first, const int i) {
                                FrameDesc d{};
                                d.N = a.N; d.edge = a.edge;
                                return fetch_sample(sig, d, (long long)first, (long long)a.rd_shift, i);
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__
     };
 
     // Work distribution: 8 contiguous ranges of steps, one per group of workgroups that share an XCD; a round
-    // of a range is 8 neighbouring steps per workgroup, drawn by its waves from the counter.
+    // of a range is NWV neighbouring steps per workgroup, drawn by its waves from the counter.
     const int xcd = blockIdx.x & 7, nwg_x = gridDim.x >> 3;
     const int s_lo = (int)((long long)a.steps * xcd / 8), s_hi = (int)((long long)a.steps * (xcd + 1) / 8);
     const int round = nwg_x * NWV, first = s_lo + (blockIdx.x >> 3) * NWV;
@@ -193,18 +206,18 @@ __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__
     if (sid >= s_hi) { return; }
     int b = sid / a.sps;
     int w = (sid - b * a.sps) * FPS;
-    const float *xb = X + (long long)b * a.ldx;
-    float *yb = Y + (long long)b * a.Wy * ROWF;
+    const T *xb = X + (long long)b * a.ldx;
+    T *yb = Y + (long long)b * a.Wy * ROWF;
 
     const unsigned cnt_addr = ring_lds_addr(ticket);
     unsigned drawn = 0;
     int nsid = 0, nw = 0;
-    const float *nxb = xb;
-    float *nyb = yb;
+    const T *nxb = xb;
+    T *nyb = yb;
     bool more = false;
     auto advance = [&]() {
         const int t = ring_drawn(drawn);
-        nsid = first + (t >> 3) * round + (t & 7);
+        nsid = first + (t / NWV) * round + (t % NWV);
         more = nsid < s_hi;
         if (more) {
             const int nb = nsid / a.sps;
@@ -220,8 +233,8 @@ __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__
     while (true) {
         ring_draw(drawn, cnt_addr);                        // the step after this one: asked for now, needed further down
         // The span of this step was asked for in the middle of the last one; memory operations complete in issue
-        // order and behind its NV loads lie that step's 6 row stores, which stay in flight.
-        if (first_step) { ring_wait_vm<0>(); } else { ring_wait_vm<NVI + 1>(); }
+        // order and behind its NV loads lie that step's row stores, which stay in flight.
+        if (first_step) { ring_wait_vm<0>(); } else { ring_wait_vm<NSTORE>(); }
         first_step = false;
         wave_sync();
 
@@ -231,37 +244,37 @@ __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__
         for (int n1 = 0; n1 < 16; ++n1) {
             if (n1 < NR) {
                 C v;
-                if constexpr (ALN) { const float2 t = *reinterpret_cast<const float2 *>(xrow + 2 * CL * n1); v = C{t.x, t.y}; }
-                else { const f2e t = *reinterpret_cast<const f2e *>(xrow + 2 * CL * n1); v = C{t.x, t.y}; }
+                if constexpr (ALN) { const pair_a t = *reinterpret_cast<const pair_a *>(xrow + 2 * CL * n1); v = C{t.x, t.y}; }
+                else { const pair_u t = *reinterpret_cast<const pair_u *>(xrow + 2 * CL * n1); v = C{t.x, t.y}; }
                 if (NR == 16 || n1 == NR - 1) {            // rows that may reach past the window: keep that data out (0 * NaN)
                     const int l = 2 * CL * n1 + 2 * j;
-                    v.x = (l < L) ? v.x : 0.f;
-                    v.y = (l + 1 < L) ? v.y : 0.f;
+                    v.x = (l < L) ? v.x : T(0);
+                    v.y = (l + 1 < L) ? v.y : T(0);
                 }
                 zz[n1] = v * hw[n1];
             } else {
-                zz[n1] = C{0.f, 0.f};
+                zz[n1] = C{T(0), T(0)};
             }
         }
         if (MN0) {
             C acc = zz[0];
 #pragma unroll
             for (int n1 = 1; n1 < NR; ++n1) { acc += zz[n1]; }
-            float sum = acc.x + acc.y;
+            T sum = acc.x + acc.y;
 #pragma unroll
             for (int m = 1; m < CL; m *= 2) { sum += __shfl_xor(sum, m); }
-            const float mean = sum / (float)L;
+            const T mean = sum / (T)L;
 #pragma unroll
             for (int n1 = 0; n1 < NR; ++n1) {
                 if (NR == 16 || n1 == NR - 1) {
                     const int l = 2 * CL * n1 + 2 * j;
-                    zz[n1] -= C{(l < L) ? mean : 0.f, (l + 1 < L) ? mean : 0.f};
+                    zz[n1] -= C{(l < L) ? mean : T(0), (l + 1 < L) ? mean : T(0)};
                 } else {
                     zz[n1] -= C{mean, mean};
                 }
             }
         }
-        dft16c<float, NR>(zz);
+        dft16c<T, NR>(zz);
         wave_sync();                                       // all lanes have read the span
         // The slot takes the next step's span.  The reads of pass 1 must have RETURNED before the first load into
         // the slot is issued (the compiler may sink their consumers, and with them its own wait, below the
@@ -270,12 +283,12 @@ __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__
         advance();
         load_span(more ? nxb : xb, step_start(more ? nw : w));
         {
-            float2 *exf = ex + f * FP + j;
+            pair_a *exf = ex + f * FP + j;
 #pragma unroll
             for (int k1 = 0; k1 < 16; ++k1) {
                 C v = zz[slot16(k1)];
-                if (k1 > 0) { v = cx_mul<float>(v, twd[k1]); }
-                exf[k1 * RP] = make_float2(v.x, v.y);
+                if (k1 > 0) { v = cx_mul<T>(v, twd[k1]); }
+                exf[k1 * RP] = pair_a{v.x, v.y};
             }
         }
         wave_sync();
@@ -284,12 +297,12 @@ __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__
         C zr[RW][CL];
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
-            const float2 *ra = ex + f * FP + (j + CL * r) * RP;
+            const pair_a *ra = ex + f * FP + (j + CL * r) * RP;
 #pragma unroll
-            for (int n2 = 0; n2 < CL; ++n2) { const float2 t = ra[n2]; zr[r][n2] = C{t.x, t.y}; }
+            for (int n2 = 0; n2 < CL; ++n2) { const pair_a t = ra[n2]; zr[r][n2] = C{t.x, t.y}; }
         }
 #pragma unroll
-        for (int r = 0; r < RW; ++r) { r256_dft_row<CL>(zr[r]); }
+        for (int r = 0; r < RW; ++r) { r256_dft_row<T, CL>(zr[r]); }
 
         // ---- real-FFT split fused with power.  zr[r][slot(k2)] = Z[K], K = j + CL r + 16 k2 (halved).
         // Partner Z[M - K]: row 16 - k1 = (CL - j) + CL (RW - 1 - r), register CL - 1 - k2: row RW - 1 - r of lane CL - j;
@@ -297,23 +310,23 @@ __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__
         // With A = Z_K + conj Z_(M-K), B = Z_K - conj Z_(M-K), T = -i W_nfft^K B:
         // |X_K|^2 = |A + T|^2 and |X_(M-K)|^2 = |A - T|^2.  K < M/2 (k2 < CL/2) covers every pair once; K = M/2 pairs with itself.
         // the step's block of rows in the output, and how it lies against 16-byte boundaries
-        float *yblk = yb + (size_t)w * ROWF;
+        T *yblk = yb + (size_t)w * ROWF;
         const int nout = __builtin_amdgcn_readfirstlane(min(FPS, a.W - w) * ROWF);
-        const int head = ring_block_head(yblk);
-        const int sh = ring_stage_shift(head);             // value e of the block is staged at xs[sh + e]
+        int head = 0, sh = 0;                              // float32: value e of the block is staged at xs[sh + e]
+        if constexpr (F32) { head = ring_block_head(yblk); sh = ring_stage_shift(head); }
         auto partner = [&](const int r, const int k2) {
             const C oth = zr[RW - 1 - r][r256_slot<CL>(CL - 1 - k2)];
             const C own = (r == 0) ? zr[0][r256_slot<CL>((CL - k2) % CL)] : zr[RW - r][r256_slot<CL>(CL - 1 - k2)];
-            const float px = r256_grp_neg<CL>(oth.x), py = r256_grp_neg<CL>(oth.y);
+            const T px = r256_grp_neg<CL>(oth.x), py = r256_grp_neg<CL>(oth.y);
             return C{(j == 0) ? own.x : px, (j == 0) ? own.y : py};
         };
         if constexpr (CPLX) {
             // X_K = A + T, X_(M-K) = conj(A - T), each written to the staging area as soon as it exists; K = M/2 is
             // 2 conj Z_(M/2) (lane j == 0)
-            const float sc = a.cscale;
+            const T sc = (T)a.cscale;
             const C zmid = zr[0][r256_slot<CL>(CL / 2)];
             wave_sync();                                   // every lane has read its tile rows (into zr): reuse the region
-            float *pf = xs + sh + f * ROWF;
+            T *pf = xs + sh + f * ROWF;
 #pragma unroll
             for (int r = 0; r < RW; ++r) {
 #pragma unroll
@@ -321,29 +334,29 @@ __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__
                     const int K = j + CL * r + 16 * k2;
                     const C z = zr[r][r256_slot<CL>(k2)];
                     const C m = partner(r, k2);
-                    const C A = cx_add_conj<float>(z, m), B = cx_sub_conj<float>(z, m);
-                    const C Tw = cx_mul<float>(B, ow[r][k2]);
+                    const C A = cx_add_conj<T>(z, m), B = cx_sub_conj<T>(z, m);
+                    const C Tw = cx_mul<T>(B, ow[r][k2]);
                     const C u = A + Tw, v = A - Tw;
                     const bool edge = (j == 0) && r == 0 && k2 == 0;     // bins 0 and M: imaginary parts zero
-                    pf[2 * K] = sc * u.x; pf[2 * K + 1] = edge ? 0.f : sc * u.y;
-                    pf[2 * (M - K)] = sc * v.x; pf[2 * (M - K) + 1] = edge ? 0.f : -sc * v.y;
+                    pf[2 * K] = sc * u.x; pf[2 * K + 1] = edge ? T(0) : sc * u.y;
+                    pf[2 * (M - K)] = sc * v.x; pf[2 * (M - K) + 1] = edge ? T(0) : -sc * v.y;
                 }
             }
-            if (j == 0) { pf[M] = 2.0f * sc * zmid.x; pf[M + 1] = -2.0f * sc * zmid.y; }
+            if (j == 0) { pf[M] = T(2) * sc * zmid.x; pf[M + 1] = T(-2) * sc * zmid.y; }
             wave_sync();
         } else {
-            float pw[16];                                      // [(r CL/2 + k2) 2]: P[K], [.. + 1]: P[M - K]
-            float pmid = 4.0f * cx_norm<float>(zr[0][r256_slot<CL>(CL / 2)]);  // K = M/2: lane j == 0 only
+            T pw[16];                                          // [(r CL/2 + k2) 2]: P[K], [.. + 1]: P[M - K]
+            T pmid = T(4) * cx_norm<T>(zr[0][r256_slot<CL>(CL / 2)]);  // K = M/2: lane j == 0 only
 #pragma unroll
             for (int r = 0; r < RW; ++r) {
 #pragma unroll
                 for (int k2 = 0; k2 < CL / 2; ++k2) {
                     const C z = zr[r][r256_slot<CL>(k2)];
                     const C m = partner(r, k2);
-                    const C A = cx_add_conj<float>(z, m), B = cx_sub_conj<float>(z, m);
-                    const C Tw = cx_mul<float>(B, ow[r][k2]);
-                    pw[(r * (CL / 2) + k2) * 2] = cx_norm<float>(A + Tw);
-                    pw[(r * (CL / 2) + k2) * 2 + 1] = cx_norm<float>(A - Tw);
+                    const C A = cx_add_conj<T>(z, m), B = cx_sub_conj<T>(z, m);
+                    const C Tw = cx_mul<T>(B, ow[r][k2]);
+                    pw[(r * (CL / 2) + k2) * 2] = cx_norm<T>(A + Tw);
+                    pw[(r * (CL / 2) + k2) * 2 + 1] = cx_norm<T>(A - Tw);
                 }
             }
             if (EPI) {
@@ -352,7 +365,7 @@ __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__
             }
             wave_sync();                                       // every lane has read its tile rows: reuse the region
             {
-                float *pf = xs + sh + f * F;
+                T *pf = xs + sh + f * F;
 #pragma unroll
                 for (int r = 0; r < RW; ++r) {
 #pragma unroll
@@ -367,9 +380,18 @@ __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__
             wave_sync();
         }
 
-        // ---- NVI + 1 stores: NVI of whole 16-byte vectors, one for the values before and after them.  Surplus
-        // lanes repeat a valid store (same value to the same address).
-        ring_store_rows<NVI>(yblk, xs + sh, head, nout, lane);
+        // ---- float32: NVI + 1 stores, NVI of whole 16-byte vectors, one for the values before and after them; float64:
+        // NSTORE element-wise stores (a wave stores 512 consecutive bytes).  Surplus lanes repeat a valid store (same value
+        // to the same address): the number of store instructions per step is fixed.
+        if constexpr (F32) {
+            ring_store_rows<NVI>(yblk, xs + sh, head, nout, lane);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NSTORE; ++i) {
+                const int e = min(lane + 64 * i, nout - 1);
+                __builtin_nontemporal_store(xs[e], yblk + e);
+            }
+        }
         if (!more) { break; }
         wave_sync();                                       // staging reads are done before the next step writes the tile
         sid = nsid; w = nw; xb = nxb; yb = nyb;
@@ -379,7 +401,8 @@ __global__ __launch_bounds__(64 * R256_WAVES, 2) void stft_r256_kernel(float *__
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-// Largest span a wave's LDS share holds beside its tile: 8 waves x (tile + span) floats + 1 KiB inside 160 KiB
+// Largest span a wave's LDS share holds beside its tile: waves x (tile + span) elements + 1 KiB inside 160 KiB (the same
+// element counts in both precisions: float64 has half the waves)
 __host__ __device__ constexpr int r256_max_span(int CL) { return CL == 2 ? 1536 : 2048; }
 // frames of a step, and how many times tbl_reach (a bound on the distance of frames w and w + 3) bounds the distance of
 // the first and last frame of a step
@@ -399,36 +422,42 @@ bool r256_supported(const FrameDesc &d)
            d.ss0 > -(1ll << 30) && d.ss0 < (1ll << 30) && d.rd_shift >= 0 && d.rd_shift < (1ll << 30);
 }
 
-template <int CL, int NR, bool MN0, bool EPI, int SPAN, bool ALN, bool CPLX = false>
-static hipError_t launch_r256_inst(float *Y, const float *X, const float *win, const float *tw, const R256Args &a, hipStream_t s)
+template <typename T, int CL, int NR, bool MN0, bool EPI, int SPAN, bool ALN, bool CPLX = false>
+static hipError_t launch_r256_inst(T *Y, const T *X, const T *win, const T *tw, const R256Args &a, hipStream_t s)
 {
     static_assert(SPAN <= r256_max_span(CL), "span too large for the LDS");
-    const size_t lds = ((size_t)R256_WAVES * (r256_tile(CL) + SPAN) + 256) * sizeof(float) + 16;
+    constexpr int NWV = r256_waves<T>();
+    const size_t lds = (size_t)NWV * (r256_tile(CL) + SPAN) * sizeof(T) + 1024 + 16;
+    static_assert((size_t)NWV * (r256_tile(CL) + SPAN) * sizeof(T) + 1024 + 16 <= 160 * 1024, "LDS of a workgroup");
     static LdsGrant grant;
-    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r256_kernel<CL, NR, MN0, EPI, SPAN, ALN, CPLX>), lds, grant); e != hipSuccess) { return e; }
-    long long grid = ((long long)a.steps + R256_WAVES - 1) / R256_WAVES;
-    if (grid > 256) { grid = 256; }                     // one 8-wave workgroup per CU
+    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r256_kernel<T, CL, NR, MN0, EPI, SPAN, ALN, CPLX>), lds, grant); e != hipSuccess) { return e; }
+    long long grid = ((long long)a.steps + NWV - 1) / NWV;
+    if (grid > 256) { grid = 256; }                     // one workgroup per CU
     grid = (grid + 7) & ~7ll;                           // whole groups of 8 workgroups (one per XCD)
-    hipLaunchKernelGGL((stft_r256_kernel<CL, NR, MN0, EPI, SPAN, ALN, CPLX>), dim3((unsigned)grid), dim3(64 * R256_WAVES), lds, s, Y, X, win, tw, a);
+    hipLaunchKernelGGL((stft_r256_kernel<T, CL, NR, MN0, EPI, SPAN, ALN, CPLX>), dim3((unsigned)grid), dim3(64 * NWV), lds, s, Y, X, win, tw, a);
     return hipGetLastError();
 }
 
-template <int CL, int NR, int SPAN, bool ALN>
-static hipError_t launch_r256_shape(float *Y, const float *X, const float *win, const float *tw, const R256Args &a, const FrameDesc &d, bool cplx, hipStream_t s)
+template <typename T, int CL, int NR, int SPAN, bool ALN>
+static hipError_t launch_r256_shape(T *Y, const T *X, const T *win, const T *tw, const R256Args &a, const FrameDesc &d, bool cplx, hipStream_t s)
 {
     const bool epi = d.epi.any();
-    if (cplx) { return launch_r256_inst<CL, NR, false, false, SPAN, ALN, true>(Y, X, win, tw, a, s); }
+    if constexpr (sizeof(T) == 4) {
+        if (cplx) { return launch_r256_inst<T, CL, NR, false, false, SPAN, ALN, true>(Y, X, win, tw, a, s); }
+    } else {
+        if (cplx) { return hipErrorInvalidValue; }      // (the complex form exists in float32 only)
+    }
 #if R256_MINIMAL
-    if (!d.mn0 && !epi) { return launch_r256_inst<CL, NR, false, false, SPAN, ALN>(Y, X, win, tw, a, s); }
+    if (!d.mn0 && !epi) { return launch_r256_inst<T, CL, NR, false, false, SPAN, ALN>(Y, X, win, tw, a, s); }
     return hipErrorInvalidValue;
 #else
-    if (d.mn0) { return epi ? launch_r256_inst<CL, NR, true, true, SPAN, ALN>(Y, X, win, tw, a, s) : launch_r256_inst<CL, NR, true, false, SPAN, ALN>(Y, X, win, tw, a, s); }
-    return epi ? launch_r256_inst<CL, NR, false, true, SPAN, ALN>(Y, X, win, tw, a, s) : launch_r256_inst<CL, NR, false, false, SPAN, ALN>(Y, X, win, tw, a, s);
+    if (d.mn0) { return epi ? launch_r256_inst<T, CL, NR, true, true, SPAN, ALN>(Y, X, win, tw, a, s) : launch_r256_inst<T, CL, NR, true, false, SPAN, ALN>(Y, X, win, tw, a, s); }
+    return epi ? launch_r256_inst<T, CL, NR, false, true, SPAN, ALN>(Y, X, win, tw, a, s) : launch_r256_inst<T, CL, NR, false, false, SPAN, ALN>(Y, X, win, tw, a, s);
 #endif
 }
 
-template <int CL>
-static hipError_t launch_r256_cl(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, bool cplx, double scale, hipStream_t s)
+template <typename T, int CL>
+static hipError_t launch_r256_cl(T *Y, const T *X, const T *win, const T *tw, const FrameDesc &d, bool cplx, double scale, hipStream_t s)
 {
     constexpr int FPS = 64 / CL, NFFT = 32 * CL, MAXS = r256_max_span(CL);
     R256Args a{};
@@ -437,33 +466,42 @@ static hipError_t launch_r256_cl(float *Y, const float *X, const float *win, con
     a.sps = (d.W + FPS - 1) / FPS;
     a.steps = d.B * a.sps;
     a.tbl = d.tbl; a.reach = 0;
-    a.cscale = (float)scale;
+    a.cscale = scale;
     if (d.tbl) {
         a.stp = 0; a.ss0 = 0; a.rd_shift = 0; a.reach = r256_reach_mult(NFFT) * d.tbl_reach;
-        return launch_r256_shape<CL, 16, MAXS, false>(Y, X, win, tw, a, d, cplx, s);
+        return launch_r256_shape<T, CL, 16, MAXS, false>(Y, X, win, tw, a, d, cplx, s);
     }
     const int reach = (FPS - 1) * d.stp + NFFT;
-    // windows that leave the last three rows of pass 1 empty (nfft 256: 193 to 208 samples, 200 = 25 ms at 8 kHz)
-    const bool nr13 = d.L > 12 * 2 * CL && d.L <= 13 * 2 * CL;
-    if (d.stp & 1) { return launch_r256_shape<CL, 16, MAXS, false>(Y, X, win, tw, a, d, cplx, s); }
-    if (reach <= 1024) {
-        return nr13 ? launch_r256_shape<CL, 13, 1024, true>(Y, X, win, tw, a, d, cplx, s)
-                    : launch_r256_shape<CL, 16, 1024, true>(Y, X, win, tw, a, d, cplx, s);
+    if (d.stp & 1) { return launch_r256_shape<T, CL, 16, MAXS, false>(Y, X, win, tw, a, d, cplx, s); }
+    if constexpr (sizeof(T) == 4) {
+        // windows that leave the last three rows of pass 1 empty (nfft 256: 193 to 208 samples, 200 = 25 ms at 8 kHz)
+        const bool nr13 = d.L > 12 * 2 * CL && d.L <= 13 * 2 * CL;
+        if (reach <= 1024) {
+            return nr13 ? launch_r256_shape<T, CL, 13, 1024, true>(Y, X, win, tw, a, d, cplx, s)
+                        : launch_r256_shape<T, CL, 16, 1024, true>(Y, X, win, tw, a, d, cplx, s);
+        }
+        if (reach <= 1280) { return launch_r256_shape<T, CL, 16, 1280, true>(Y, X, win, tw, a, d, cplx, s); }
+    } else {
+        if (reach <= 1024) { return launch_r256_shape<T, CL, 16, 1024, true>(Y, X, win, tw, a, d, cplx, s); }
     }
-    if (reach <= 1280) { return launch_r256_shape<CL, 16, 1280, true>(Y, X, win, tw, a, d, cplx, s); }
-    return launch_r256_shape<CL, 16, MAXS, true>(Y, X, win, tw, a, d, cplx, s);
+    return launch_r256_shape<T, CL, 16, MAXS, true>(Y, X, win, tw, a, d, cplx, s);
 }
 
-static hipError_t launch_r256_any(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, bool cplx, double scale, hipStream_t s)
+template <typename T>
+static hipError_t launch_r256_any(T *Y, const T *X, const T *win, const T *tw, const FrameDesc &d, bool cplx, double scale, hipStream_t s)
 {
-    if (d.nfft == 256) { return launch_r256_cl<8>(Y, X, win, tw, d, cplx, scale, s); }
-    if (d.nfft == 128) { return launch_r256_cl<4>(Y, X, win, tw, d, cplx, scale, s); }
-    return launch_r256_cl<2>(Y, X, win, tw, d, cplx, scale, s);
+    if (d.nfft == 256) { return launch_r256_cl<T, 8>(Y, X, win, tw, d, cplx, scale, s); }
+    if (d.nfft == 128) { return launch_r256_cl<T, 4>(Y, X, win, tw, d, cplx, scale, s); }
+    return launch_r256_cl<T, 2>(Y, X, win, tw, d, cplx, scale, s);
 }
 
 hipError_t launch_stft_r256(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, hipStream_t s)
 {
-    return launch_r256_any(Y, X, win, tw, d, false, 0.0, s);
+    return launch_r256_any<float>(Y, X, win, tw, d, false, 0.0, s);
+}
+hipError_t launch_stft_r256(double *Y, const double *X, const double *win, const double *tw, const FrameDesc &d, hipStream_t s)
+{
+    return launch_r256_any<double>(Y, X, win, tw, d, false, 0.0, s);
 }
 
 // The complex form: Y[b][w][nfft/2 + 1] interleaved (re, im) pairs times `scale`; equally spaced frames, no mean removal.
@@ -474,7 +512,7 @@ bool r256_cplx_supported(const FrameDesc &d)
 
 hipError_t launch_stft_r256_cplx(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, double scale, hipStream_t s)
 {
-    return launch_r256_any(Y, X, win, tw, d, true, scale, s);
+    return launch_r256_any<float>(Y, X, win, tw, d, true, scale, s);
 }
 
 }  // namespace dsp

@@ -69,37 +69,39 @@ __device__ __forceinline__ void ring_store_rows(float *__restrict__ yblk, const 
 
 // ---- one span into a wave's slot: NV LDS-DMA loads whatever the case (a counted wait relies on that) -----------
 // Samples s0 .. s0 + need of the signal at xb (read at s0 - rd_shift under the zero-edge rule).  Inside the signal:
-// NV wave loads of 1 KiB, lanes past the last vector that is used (nvec = ceil(need / 4)) read that vector again.
-// A span that crosses an edge of its signal is gathered sample by sample (reflection or zeros) and NV placeholder
-// loads follow, from the first KiB of `tw` into `dummy`.
-template <int NV, typename FETCH>
-__device__ __forceinline__ void ring_load_span(float *slot, float *dummy, const float *tw, const float *xb, const int s0, const int need,
+// NV wave loads of 1 KiB, lanes past the last vector that is used (nvec = ceil(need / VEC), VEC = 16 bytes of samples)
+// read that vector again.  A span that crosses an edge of its signal is gathered sample by sample (reflection or zeros)
+// and NV placeholder loads follow, from the first KiB of `tw` into `dummy`.
+template <int NV, typename T, typename FETCH>
+__device__ __forceinline__ void ring_load_span(T *slot, T *dummy, const T *tw, const T *xb, const int s0, const int need,
                                                const int N, const int edge, const int rd_shift, const int lane, FETCH fetch)
 {
-    const int nvec = (need + 3) / 4;
-    const float *src = xb + (s0 - (edge ? rd_shift : 0));
-    const bool inside = s0 >= 0 && s0 + 4 * nvec <= N && (edge == 0 || s0 >= rd_shift);
+    constexpr int VEC = 16 / (int)sizeof(T);
+    typedef T vecT __attribute__((ext_vector_type(VEC)));
+    const int nvec = (need + VEC - 1) / VEC;
+    const T *src = xb + (s0 - (edge ? rd_shift : 0));
+    const bool inside = s0 >= 0 && s0 + VEC * nvec <= N && (edge == 0 || s0 >= rd_shift);
     if (inside) {
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
 #ifdef RING_FAKE_NV
             if (q >= RING_FAKE_NV) { continue; }       // diagnostic builds: fewer loads (wrong results)
 #endif
-            ring_glds16(src + min(q * 64 + lane, nvec - 1) * 4, __builtin_amdgcn_readfirstlane(ring_lds_addr(slot + q * 256)));
+            ring_glds16(src + min(q * 64 + lane, nvec - 1) * VEC, __builtin_amdgcn_readfirstlane(ring_lds_addr(slot + q * 64 * VEC)));
         }
     } else {
 #pragma clang loop unroll(disable)
         for (int q = 0; q < NV; ++q) {
-            float t[4];
+            vecT t;
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int i = (q * 64 + lane) * 4 + v;
-                t[v] = (i < need) ? fetch(xb, s0, i) : 0.f;
+            for (int v = 0; v < VEC; ++v) {
+                const int i = (q * 64 + lane) * VEC + v;
+                t[v] = (i < need) ? fetch(xb, s0, i) : T(0);
             }
-            reinterpret_cast<float4 *>(slot)[q * 64 + lane] = make_float4(t[0], t[1], t[2], t[3]);
+            reinterpret_cast<vecT *>(slot)[q * 64 + lane] = t;
         }
 #pragma unroll
-        for (int q = 0; q < NV; ++q) { ring_glds16(tw + lane * 4, __builtin_amdgcn_readfirstlane(ring_lds_addr(dummy))); }
+        for (int q = 0; q < NV; ++q) { ring_glds16(tw + lane * VEC, __builtin_amdgcn_readfirstlane(ring_lds_addr(dummy))); }
     }
 }
 

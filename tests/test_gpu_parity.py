@@ -163,8 +163,7 @@ def test_256_1024_2048_kernels_agree_with_oracle(O, D):
     import torch
     dt = np.float32
     assert D.kernel_family(1024, dt) == 6 and D.kernel_family(2048, dt) == 6 and D.kernel_family(1024, np.float64) == 5
-    assert D.kernel_family(256, dt) == 7 and D.kernel_family(256, np.float64) == 5
-    assert D.kernel_family(128, dt) == 7 and D.kernel_family(64, dt) == 7 and D.kernel_family(32, dt) == 5 and D.kernel_family(128, np.float64) == 5
+    assert D.kernel_family(256, dt) == 7 and D.kernel_family(128, dt) == 7 and D.kernel_family(64, dt) == 7 and D.kernel_family(32, dt) == 5
     shapes = [(128, 128, 32, (0, 0, 0)), (128, 100, 40, (1, 0, 0)), (128, 127, 17, (0, 1, 0)), (128, 65, 128, (1, 1, 1)), (128, 104, 73, (0, 0, 1)),
               (128, 97, 129, (0, 0, 0)), (128, 2, 1, (1, 0, 0)), (128, 128, 64, (0, 0, 0)),
               (64, 64, 16, (0, 0, 0)), (64, 50, 20, (1, 0, 0)), (64, 63, 9, (0, 1, 0)), (64, 33, 47, (1, 1, 1)), (64, 52, 48, (0, 0, 1)),
@@ -230,6 +229,70 @@ def test_256_1024_2048_kernels_agree_with_oracle(O, D):
                     assert rc == 0
                     Y = D.stft_flt(x, win, W, c0, stp, nfft=nfft)
                     check_spec(O, Y, Yref.astype(dt))
+            finally:
+                D.set_flt_mode(False)
+
+
+def test_64_128_256_kernels_float64(O, D):
+    """The float64 form of the nfft 64 / 128 / 256 kernel (family 7; 4 waves per workgroup, rows stored element by
+    element): the shapes of the float32 test (full, short and odd windows, hops of every alignment up to the span limit and
+    past it, every flag, both edge rules, a signal shorter than the window), outputs at both 8-byte alignments with the
+    bytes around them untouched, bit-equal repeats on a full grid, stft_flt with whole and fractional hops in both framings."""
+    import torch
+    dt = np.float64
+    assert D.kernel_family(256, dt) == 7 and D.kernel_family(128, dt) == 7 and D.kernel_family(64, dt) == 7 and D.kernel_family(1024, dt) == 5
+    shapes = [(256, 256, 64, (0, 0, 0)), (256, 200, 80, (1, 0, 0)), (256, 255, 33, (0, 1, 0)), (256, 129, 256, (1, 1, 1)), (256, 208, 146, (0, 0, 1)),
+              (256, 193, 257, (0, 0, 0)), (256, 2, 1, (1, 0, 0)),
+              (128, 128, 32, (0, 0, 0)), (128, 100, 40, (1, 0, 0)), (128, 127, 17, (0, 1, 0)), (128, 65, 128, (1, 1, 1)), (128, 104, 73, (0, 0, 1)),
+              (128, 97, 129, (0, 0, 0)), (128, 2, 1, (1, 0, 0)), (128, 128, 64, (0, 0, 0)),
+              (64, 64, 16, (0, 0, 0)), (64, 50, 20, (1, 0, 0)), (64, 63, 9, (0, 1, 0)), (64, 33, 47, (1, 1, 1)), (64, 52, 48, (0, 0, 1)),
+              (64, 49, 64, (0, 0, 0)), (64, 2, 1, (1, 0, 0)), (64, 64, 32, (0, 1, 1))]
+    for (nfft, L, stp, flags) in shapes:
+        for N in (max(12 * nfft + 77, 3001) if stp > 1 else nfft + 300, L // 2 + 1):
+            x = signal(nfft + N + stp, N, dt) + dt(0.15)
+            win = D.povey(L, dt)
+            for snip in (0, 1):
+                if snip and L > N:
+                    continue
+                rc, Yref = O.stft(x, win, stp, nfft, snip, *flags)
+                assert rc == 0
+                Y = D.stft(x, win, stp, bool(snip), *[bool(f) for f in flags], nfft=nfft)
+                check_spec(O, Y, Yref, flags[1], flags[2])
+    for (nfft, stp, N) in [(64, 16, 3000), (64, 20, 2777), (128, 40, 5000), (128, 32, 4157), (256, 80, 5000), (256, 64, 4157)]:
+        xs = np.stack([signal(10 * k + nfft, N, dt) for k in range(3)])
+        win = D.hann(nfft, dt)
+        want = np.stack([O.stft(r, win, stp, nfft, 0)[1] for r in xs])
+        xd, wd = torch.from_numpy(xs).cuda(), torch.from_numpy(win).cuda()
+        for off in (0, 1):
+            buf = torch.full((want.size + 4,), 7.0, dtype=torch.float64, device="cuda")
+            out = buf[off:off + want.size].view(want.shape)
+            D.stft_dev(xd, wd, stp, nfft=nfft, out=out)
+            torch.cuda.synchronize()
+            check_spec(O, out.cpu().numpy(), want)
+            assert float(buf[:off].sum()) == 7.0 * off and bool((buf[off + want.size:] == 7.0).all())
+    for (nfft, stp) in [(64, 16), (128, 40), (256, 80)]:
+        xd = torch.randn((64, 1 << 19), device="cuda", dtype=torch.float64, generator=torch.Generator(device="cuda").manual_seed(nfft))
+        wd = torch.from_numpy(D.hann(nfft, dt)).cuda()
+        y0 = D.stft_dev(xd, wd, stp, nfft=nfft)
+        y1 = torch.empty_like(y0)
+        for _ in range(5):
+            D.stft_dev(xd, wd, stp, nfft=nfft, out=y1)
+            assert torch.equal(y0, y1)
+        alone = D.stft_dev(xd[37:38].clone(), wd, stp, nfft=nfft)
+        assert torch.equal(alone[0], y0[37])
+        del xd, y0, y1
+    x = signal(78, 30000, dt)
+    for nfft in (64, 128, 256):
+        win = D.blackmanharris(nfft, dt)
+        for intended in (False, True):
+            D.set_flt_mode(intended)
+            try:
+                for (c0, stp, W) in [(0.0, nfft / 4.0, 75), (-3.0 * nfft, nfft / 2.0, 41), (100.0, nfft / 4.0 + 0.5, 67), (29000.0, nfft / 4.0 + 0.25, 70),
+                                     (700.0, 300.0, 40)]:
+                    rc, Yref = O.stft_flt(x, win, W, c0, stp, nfft, 0, 0, 0, intended=intended)
+                    assert rc == 0
+                    Y = D.stft_flt(x, win, W, c0, stp, nfft=nfft)
+                    check_spec(O, Y, Yref)
             finally:
                 D.set_flt_mode(False)
 

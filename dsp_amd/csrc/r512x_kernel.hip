@@ -1,4 +1,4 @@
-// Fused STFT kernel for nfft = 1024 and 2048, float32, equally spaced frames (gfx950): the 256-point complex
+// Fused STFT kernel for nfft = 1024 and 2048, float32 and float64 (gfx950): the 256-point complex
 // engine of the 512-point kernel (16 lanes, 16 values each: a 16 x 16 four-step transform with one exchange
 // through LDS) under one decimation-in-frequency stage of radix Q = nfft / 512.
 //
@@ -21,6 +21,9 @@
 // the staging is shifted to put the 16-byte boundaries of the OUTPUT on 16-byte boundaries of the LDS, the
 // body leaves as four vector stores and the 0 to 3 values before and after it as one more instruction: five
 // stores per step whatever the alignment, which keeps the counted wait for the next span exact.
+// float64: the same source with 4 waves per workgroup (twice the bytes per wave in the LDS; one wave per SIMD has the
+// registers for every per-lane table in double), lane moves as two 32-bit moves per value, rows stored element-wise (17
+// store instructions per step).
 #include "stft_common.h"
 #include "fft16.h"
 #include "span_ring.h"
@@ -42,14 +45,14 @@ struct R512XArgs {
     int steps;            // B * sps
     const int *tbl;       // table form: start of frame w at tbl[2 w] (frames need not be equally spaced); else nullptr
     int reach;            // table form: bound on the distance between the starts of the first and last frame of a step
-    float cscale;         // complex form: factor on every output value
+    double cscale;        // complex form: factor on every output value
 };
 
 constexpr int R512X_TILE = 4 * R512_EXF * 2;          // floats of a wave's exchange tile / row staging
-constexpr int R512X_WAVES = 8;
+template <typename T> __host__ __device__ constexpr int r512x_waves() { return sizeof(T) == 4 ? 8 : 4; }   // per workgroup
 
 #ifndef R512X_TWD_LDS
-#define R512X_TWD_LDS (Q == 4 || SPAN == 2048)   // where the pass-1 twiddles of the 256-point transform come from an LDS table instead of 30 registers (these instantiations spill otherwise; measured: 1024 / hop 512 0.480 -> 0.449 ms, and 6 % slower where nothing spills)
+#define R512X_TWD_LDS (sizeof(T) == 4 && (Q == 4 || SPAN == 2048))   // where the pass-1 twiddles of the 256-point transform come from an LDS table instead of 30 registers (these instantiations spill otherwise; measured: 1024 / hop 512 0.480 -> 0.449 ms, and 6 % slower where nothing spills)
 #endif
 #ifndef R512X_TWD_AHEAD
 #define R512X_TWD_AHEAD 1       // 1: the LDS twiddles of a step are read in one go before the pass-1 transform
@@ -112,21 +115,54 @@ __device__ __forceinline__ void r512x_swap32(cx<float> &a, cx<float> &b)
     b = cx<float>{__uint_as_float(tx.y), __uint_as_float(ty.y)};
 }
 
+// the same moves on doubles: the two 32-bit halves separately
+__device__ __forceinline__ double r512x_mirror(double v)
+{
+    return __hiloint2double(__float_as_int(r512x_mirror(__int_as_float(__double2hiint(v)))), __float_as_int(r512x_mirror(__int_as_float(__double2loint(v)))));
+}
+__device__ __forceinline__ double r512x_ror1(double v)
+{
+    return __hiloint2double(__float_as_int(r512x_ror1(__int_as_float(__double2hiint(v)))), __float_as_int(r512x_ror1(__int_as_float(__double2loint(v)))));
+}
+__device__ __forceinline__ double r512x_xor32(double v, bool low_half)
+{
+    return __hiloint2double(__float_as_int(r512x_xor32(__int_as_float(__double2hiint(v)), low_half)), __float_as_int(r512x_xor32(__int_as_float(__double2loint(v)), low_half)));
+}
+__device__ __forceinline__ void r512x_swap16(double &a, double &b)
+{
+    const r512x_u2 tl = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const r512x_u2 th = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)th.x, (int)tl.x);
+    b = __hiloint2double((int)th.y, (int)tl.y);
+}
+__device__ __forceinline__ void r512x_swap32(double &a, double &b)
+{
+    const r512x_u2 tl = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const r512x_u2 th = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)th.x, (int)tl.x);
+    b = __hiloint2double((int)th.y, (int)tl.y);
+}
+__device__ __forceinline__ void r512x_swap16(cx<double> &a, cx<double> &b) { r512x_swap16(a.x, b.x); r512x_swap16(a.y, b.y); }
+__device__ __forceinline__ void r512x_swap32(cx<double> &a, cx<double> &b) { r512x_swap32(a.x, b.x); r512x_swap32(a.y, b.y); }
+
 // CPLX: the rows are the complex spectra (M + 1 interleaved (re, im) pairs per frame, the imaginary parts of the first and
 // last zero: window_univar followed by fft_fftw_r2hc, reference c/window_univar.c:41-89, c/fft.fftw.r2hc.c:69-78) instead of
 // their powers.
-template <int Q, bool FULL, bool MN0, bool EPI, int SPAN, bool ALN, bool CPLX = false>
-__global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *__restrict__ Y, const float *__restrict__ X,
-                                                                         const float *__restrict__ win, const float *__restrict__ tw,
-                                                                         const R512XArgs a)
+template <typename T, int Q, bool FULL, bool MN0, bool EPI, int SPAN, bool ALN, bool CPLX = false>
+__global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void stft_r512x_kernel(T *__restrict__ Y, const T *__restrict__ X,
+                                                                                               const T *__restrict__ win, const T *__restrict__ tw,
+                                                                                               const R512XArgs a)
 {
     static_assert(Q == 2 || Q == 4, "nfft 1024 or 2048");
-    using C = cx<float>;
-    typedef float f2e __attribute__((ext_vector_type(2), aligned(4)));
-    constexpr int NFFT = 512 * Q, M = 256 * Q, F = M + 1, FPS = 4 / Q, NWV = R512X_WAVES, NV = SPAN / 256;
+    using C = cx<T>;
+    typedef T pair_u __attribute__((ext_vector_type(2), aligned(sizeof(T))));        // a pair of samples at sample alignment
+    typedef T pair_a __attribute__((ext_vector_type(2), aligned(2 * sizeof(T))));    // ... at its own alignment
+    constexpr bool F32 = sizeof(T) == 4;
+    constexpr int NFFT = 512 * Q, M = 256 * Q, F = M + 1, FPS = 4 / Q, NWV = r512x_waves<T>(), NV = SPAN * (int)sizeof(T) / 1024;
     constexpr int WAVE_LDS = R512X_TILE + SPAN;
-    constexpr int ROWF = CPLX ? 2 * F : F;                 // floats of an output row
-    constexpr int NVI = (FPS * ROWF + 255) / 256;          // whole-vector wave stores of a step's block of rows
+    constexpr int ROWF = CPLX ? 2 * F : F;                 // values of an output row
+    constexpr int NVI = (FPS * ROWF + 255) / 256;          // float32: whole-vector wave stores of a step's block of rows
+    constexpr int NSTORE = F32 ? NVI + 1 : (FPS * ROWF + 63) / 64;   // store instructions per step
     static_assert(FPS * ROWF + 3 <= R512X_TILE, "row staging fits the tile");
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -137,17 +173,17 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
     constexpr int R = 16 / Q;                              // rows of the input stage per group
     const int L = a.L;
 
-    float *xs = reinterpret_cast<float *>(smem_raw) + wv * WAVE_LDS;   // exchange tile, then row staging
-    float2 *ex = reinterpret_cast<float2 *>(xs);
-    float *slot = xs + R512X_TILE;                                     // the span
-    float2 *ttab = reinterpret_cast<float2 *>(reinterpret_cast<float *>(smem_raw) + NWV * WAVE_LDS);   // W256^(j k1) at [k1][j]
-    float *dummy = reinterpret_cast<float *>(ttab + (R512X_TWD_LDS ? 256 : 0));   // 1 KiB that placeholder LDS-DMA loads write
-    unsigned *ticket = reinterpret_cast<unsigned *>(dummy + 256);
+    T *xs = reinterpret_cast<T *>(smem_raw) + wv * WAVE_LDS;           // exchange tile, then row staging
+    pair_a *ex = reinterpret_cast<pair_a *>(xs);
+    T *slot = xs + R512X_TILE;                                         // the span
+    pair_a *ttab = reinterpret_cast<pair_a *>(reinterpret_cast<T *>(smem_raw) + NWV * WAVE_LDS);   // W256^(j k1) at [k1][j]
+    unsigned char *dummy = reinterpret_cast<unsigned char *>(ttab + (R512X_TWD_LDS ? 256 : 0));   // 1 KiB that placeholder LDS-DMA loads write
+    unsigned *ticket = reinterpret_cast<unsigned *>(dummy + 1024);
 
     // ---- per-lane constants ----
     auto twn = [&](int idx) {                              // W_nfft^idx, idx < nfft (the table holds idx < M)
-        float sg = 1.0f;
-        if (idx >= M) { idx -= M; sg = -1.0f; }
+        T sg = T(1);
+        if (idx >= M) { idx -= M; sg = T(-1); }
         return C{sg * tw[2 * idx], sg * tw[2 * idx + 1]};
     };
     C twd[16];                                             // W256^(j k1)
@@ -156,7 +192,7 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
         for (int k1 = 1; k1 < 16; ++k1) { twd[k1] = twn(2 * Q * j * k1); }
     } else if (tid < 256) {
         const C t = twn(2 * Q * (tid & 15) * (tid >> 4));
-        ttab[tid] = make_float2(t.x, t.y);
+        ttab[tid] = pair_a{t.x, t.y};
     }
     // input stage: row i of the group is n1 = Q i + g, i.e. m = j + 16 n1; halved window taps of its Q quarters
     // and the twiddles W_M^(m rr), rr = 1 .. Q - 1
@@ -167,7 +203,7 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             const int l = 2 * m + 512 * q;
-            hw[Q * i + q] = C{(l < L) ? 0.5f * win[l] : 0.f, (l + 1 < L) ? 0.5f * win[l + 1] : 0.f};
+            hw[Q * i + q] = C{(l < L) ? T(0.5) * win[l] : T(0), (l + 1 < L) ? T(0.5) * win[l + 1] : T(0)};
         }
 #pragma unroll
         for (int rr = 1; rr < Q; ++rr) { dt[(Q - 1) * i + rr - 1] = twn((2 * m * rr) & (NFFT - 1)); }
@@ -180,7 +216,7 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
 
     const int reach = a.tbl ? a.reach : (FPS - 1) * a.stp;
     const int need = reach + L;                            // samples of a span that pass 1 uses
-    const float *xrow = slot + f * a.stp + 2 * j + 32 * g;   // row i, quarter q at xrow[32 Q i + 512 q]
+    const T *xrow = slot + f * a.stp + 2 * j + 32 * g;   // row i, quarter q at xrow[32 Q i + 512 q]
     // Start of the span of the step at frame w_ (wave-uniform).  Table form: the starts of the step's frames by
     // scalar loads (a vector load would put the compiler's own wait for ALL outstanding memory operations, the row
     // stores included, in front of the span fetch), and xrow for that step: called when pass 1 is done with the last one.
@@ -197,9 +233,9 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
 
     // ---- fetch of one span into the slot: NV LDS-DMA loads whatever the case (the counted wait relies on
     // that); a span that crosses an edge of its signal is gathered sample by sample and NV placeholder loads follow
-    auto load_span = [&](const float *xb, const int s0) {
-        ring_load_span<NV>(slot, dummy, tw, R512X_NOLOAD ? tw - (s0 - (a.edge ? a.rd_shift : 0)) : xb, s0, need, a.N, a.edge, a.rd_shift, lane,
-                           [&](const float *sig, const int first, const int i) {
+    auto load_span = [&](const T *xb, const int s0) {
+        ring_load_span<NV>(slot, reinterpret_cast<T *>(dummy), tw, R512X_NOLOAD ? tw - (s0 - (a.edge ? a.rd_shift : 0)) : xb, s0, need, a.N, a.edge, a.rd_shift, lane,
+                           [&](const T *sig, const int first, const int i) {
                                FrameDesc d{};
                                d.N = a.N; d.edge = a.edge;
                                return fetch_sample(sig, d, (long long)first, (long long)a.rd_shift, i);
@@ -215,18 +251,18 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
     if (sid >= s_hi) { return; }
     int b = sid / a.sps;
     int w = (sid - b * a.sps) * FPS;
-    const float *xb = X + (long long)b * a.ldx;
-    float *yb = Y + (long long)b * a.Wy * ROWF;
+    const T *xb = X + (long long)b * a.ldx;
+    T *yb = Y + (long long)b * a.Wy * ROWF;
 
     const unsigned cnt_addr = ring_lds_addr(ticket);
     unsigned drawn = 0;
     int nsid = 0, nw = 0;
-    const float *nxb = xb;
-    float *nyb = yb;
+    const T *nxb = xb;
+    T *nyb = yb;
     bool more = false;
     auto advance = [&]() {
         const int t = ring_drawn(drawn);
-        nsid = first + (t >> 3) * round + (t & 7);
+        nsid = first + (t / NWV) * round + (t % NWV);
         more = nsid < s_hi;
         if (more) {
             const int nb = nsid / a.sps;
@@ -247,7 +283,7 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
         ring_draw(drawn, cnt_addr);                       // the step after this one: asked for now, needed further down
         // The span of this step was asked for in the middle of the last one; memory operations complete in issue
         // order and behind its NV loads lie that step's 5 row stores, which stay in flight.
-        if (first_step) { ring_wait_vm<0>(); } else { ring_wait_vm<NVI + 1>(); }
+        if (first_step) { ring_wait_vm<0>(); } else { ring_wait_vm<NSTORE>(); }
         first_step = false;
         wave_sync();
         R512X_STAMP(0);                                    // wait for the span
@@ -260,14 +296,14 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
             for (int i = 0; i < R; ++i) {
 #pragma unroll
                 for (int q = 0; q < Q; ++q) {
-                    const float *p = xrow + 32 * Q * i + 512 * q;
+                    const T *p = xrow + 32 * Q * i + 512 * q;
                     C v;
-                    if constexpr (ALN) { const float2 t = *reinterpret_cast<const float2 *>(p); v = C{t.x, t.y}; }
-                    else { const f2e t = *reinterpret_cast<const f2e *>(p); v = C{t.x, t.y}; }
+                    if constexpr (ALN) { const pair_a t = *reinterpret_cast<const pair_a *>(p); v = C{t.x, t.y}; }
+                    else { const pair_u t = *reinterpret_cast<const pair_u *>(p); v = C{t.x, t.y}; }
                     if (!FULL) {                           // keep data past the window out (0 * NaN)
                         const int l = 2 * j + 32 * (Q * i + g) + 512 * q;
-                        v.x = (l < L) ? v.x : 0.f;
-                        v.y = (l + 1 < L) ? v.y : 0.f;
+                        v.x = (l < L) ? v.x : T(0);
+                        v.y = (l + 1 < L) ? v.y : T(0);
                     }
                     A[Q * i + q] = v * hw[Q * i + q];
                 }
@@ -276,16 +312,16 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
                 C acc = A[0];
 #pragma unroll
                 for (int i = 1; i < 16; ++i) { acc += A[i]; }
-                float sum = acc.x + acc.y;
+                T sum = acc.x + acc.y;
 #pragma unroll
                 for (int o = 1; o < 16 * Q; o <<= 1) { sum += __shfl_xor(sum, o); }
-                const float mean = sum / (float)L;
+                const T mean = sum / (T)L;
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
 #pragma unroll
                     for (int q = 0; q < Q; ++q) {
                         const int l = 2 * j + 32 * (Q * i + g) + 512 * q;
-                        A[Q * i + q] -= C{(FULL || l < L) ? mean : 0.f, (FULL || l + 1 < L) ? mean : 0.f};
+                        A[Q * i + q] -= C{(FULL || l < L) ? mean : T(0), (FULL || l + 1 < L) ? mean : T(0)};
                     }
                 }
             }
@@ -293,7 +329,7 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
                     C o0 = A[2 * i] + A[2 * i + 1];
-                    C o1 = cx_mul<float>(A[2 * i] - A[2 * i + 1], dt[i]);
+                    C o1 = cx_mul<T>(A[2 * i] - A[2 * i + 1], dt[i]);
                     // the even rows of lanes (g = 0) keep the odd bins of their own rows and get those of the other
                     // group's rows; the odd rows of lanes the even bins
                     r512x_swap16(o1, o0);
@@ -303,9 +339,9 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
             } else {
 #pragma unroll
                 for (int i = 0; i < R; ++i) {
-                    dft4c<float>(A[4 * i], A[4 * i + 1], A[4 * i + 2], A[4 * i + 3]);
+                    dft4c<T>(A[4 * i], A[4 * i + 1], A[4 * i + 2], A[4 * i + 3]);
 #pragma unroll
-                    for (int rr = 1; rr < 4; ++rr) { A[4 * i + rr] = cx_mul<float>(A[4 * i + rr], dt[3 * i + rr - 1]); }
+                    for (int rr = 1; rr < 4; ++rr) { A[4 * i + rr] = cx_mul<T>(A[4 * i + rr], dt[3 * i + rr - 1]); }
                     // neighbouring rows of lanes trade the low bit of the residue ...
                     r512x_swap16(A[4 * i + 1], A[4 * i + 0]);
                     r512x_swap16(A[4 * i + 3], A[4 * i + 2]);
@@ -327,10 +363,10 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
         C twl[16];
         if constexpr (R512X_TWD_LDS && R512X_TWD_AHEAD) {
 #pragma unroll
-            for (int k1 = 1; k1 < 16; ++k1) { const float2 t = ttab[k1 * 16 + j]; twl[k1] = C{t.x, t.y}; }
+            for (int k1 = 1; k1 < 16; ++k1) { const pair_a t = ttab[k1 * 16 + j]; twl[k1] = C{t.x, t.y}; }
             __builtin_amdgcn_sched_barrier(0);             // (the scheduler would sink the reads below the transform)
         }
-        dft16c<float, 16>(zz);
+        dft16c<T, 16>(zz);
         wave_sync();                                       // all lanes have read the span
         // The slot takes the next step's span.  The reads of pass 1 must have RETURNED before the first load into
         // the slot is issued (the compiler may sink their consumers, and with them its own wait, below the
@@ -340,16 +376,16 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
         load_span(more ? nxb : xb, step_start(more ? nw : w));
         R512X_STAMP(2);                                    // pass-1 transform, draw, span fetch issued
         {
-            float2 *exf = ex + grp * R512_EXF + j;
+            pair_a *exf = ex + grp * R512_EXF + j;
 #pragma unroll
             for (int k1 = 0; k1 < 16; ++k1) {
                 C v = zz[slot16(k1)];
                 if (k1 > 0) {
-                    if constexpr (R512X_TWD_LDS && R512X_TWD_AHEAD) { v = cx_mul<float>(v, twl[k1]); }
-                    else if constexpr (R512X_TWD_LDS) { const float2 t = ttab[k1 * 16 + j]; v = cx_mul<float>(v, t.x, t.y); }
-                    else { v = cx_mul<float>(v, twd[k1]); }
+                    if constexpr (R512X_TWD_LDS && R512X_TWD_AHEAD) { v = cx_mul<T>(v, twl[k1]); }
+                    else if constexpr (R512X_TWD_LDS) { const pair_a t = ttab[k1 * 16 + j]; v = cx_mul<T>(v, t.x, t.y); }
+                    else { v = cx_mul<T>(v, twd[k1]); }
                 }
-                exf[k1 * 17] = make_float2(v.x, v.y);
+                exf[k1 * 17] = pair_a{v.x, v.y};
             }
         }
         wave_sync();
@@ -357,11 +393,11 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
 
         // ---- pass 2: lane (group, k1 = j): 16-point FFT over the columns ----
         {
-            const float2 *exf = ex + grp * R512_EXF + j * 17;
+            const pair_a *exf = ex + grp * R512_EXF + j * 17;
 #pragma unroll
-            for (int n2 = 0; n2 < 16; ++n2) { const float2 t = exf[n2]; zz[n2] = C{t.x, t.y}; }
+            for (int n2 = 0; n2 < 16; ++n2) { const pair_a t = exf[n2]; zz[n2] = C{t.x, t.y}; }
         }
-        dft16c<float, 16>(zz);
+        dft16c<T, 16>(zz);
 
         // ---- real-FFT split fused with power.  The lane holds Z[K] (halved), K = Q (j + 16 k2) + r, in
         // register k2.  Z[M - K] is, for r = 0: register 15 - k2 of lane (16 - j) % 16 (register (16 - k2) % 16
@@ -370,66 +406,66 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
         // |X_K|^2 = |A + T|^2 and |X_(M-K)|^2 = |A - T|^2.
         R512X_STAMP(4);                                    // pass-2 reads and transform
         // the step's block of rows in the output, and how it lies against 16-byte boundaries
-        float *yblk = yb + (size_t)w * ROWF;
+        T *yblk = yb + (size_t)w * ROWF;
         const int nout = __builtin_amdgcn_readfirstlane(min(FPS, a.W - w) * ROWF);
-        const int head = ring_block_head(yblk);
-        const int sh = ring_stage_shift(head);             // value e of the block is staged at xs[sh + e]
+        int head = 0, sh = 0;                              // float32: value e of the block is staged at xs[sh + e]
+        if constexpr (F32) { head = ring_block_head(yblk); sh = ring_stage_shift(head); }
         const bool own0 = (r == 0) && (j == 0);
         if constexpr (CPLX) {
             // X_K = A + T, X_(M-K) = conj(A - T), each written to the staging area as soon as it exists; K = M / 2 is
             // 2 conj Z_(M/2) (lane 0 of residue 0)
-            const float sc = a.cscale;
+            const T sc = (T)a.cscale;
             const C zmid = zz[slot16(8)];
             wave_sync();                                   // every lane has read its tile row (into zz): reuse the region
-            float *pf = xs + sh + f * ROWF;
+            T *pf = xs + sh + f * ROWF;
 #pragma unroll
             for (int k2 = 0; k2 < 8; ++k2) {
                 const C z = zz[slot16(k2)];
                 const C own = zz[slot16((16 - k2) & 15)], oth = zz[slot16(15 - k2)];
-                const float mx1 = r512x_mirror(oth.x), my1 = r512x_mirror(oth.y);
-                const float mx2 = r512x_ror1(mx1), my2 = r512x_ror1(my1);
+                const T mx1 = r512x_mirror(oth.x), my1 = r512x_mirror(oth.y);
+                const T mx2 = r512x_ror1(mx1), my2 = r512x_ror1(my1);
                 C m;
                 if constexpr (Q == 2) {
                     m = C{r == 0 ? mx2 : mx1, r == 0 ? my2 : my1};
                 } else {
-                    const float mx3 = r512x_xor32(mx1, lane < 32), my3 = r512x_xor32(my1, lane < 32);
+                    const T mx3 = r512x_xor32(mx1, lane < 32), my3 = r512x_xor32(my1, lane < 32);
                     m = C{r == 0 ? mx2 : (r == 2 ? mx1 : mx3), r == 0 ? my2 : (r == 2 ? my1 : my3)};
                 }
                 m = C{own0 ? own.x : m.x, own0 ? own.y : m.y};
-                const C A = cx_add_conj<float>(z, m), B = cx_sub_conj<float>(z, m);
-                const C Tw = cx_mul<float>(B, ow[k2]);
+                const C A = cx_add_conj<T>(z, m), B = cx_sub_conj<T>(z, m);
+                const C Tw = cx_mul<T>(B, ow[k2]);
                 const C u = A + Tw, v = A - Tw;
                 const int K = Q * (j + 16 * k2) + r;
                 const bool edge = own0 && k2 == 0;         // bins 0 and M: imaginary parts zero
-                pf[2 * K] = sc * u.x; pf[2 * K + 1] = edge ? 0.f : sc * u.y;
-                pf[2 * (M - K)] = sc * v.x; pf[2 * (M - K) + 1] = edge ? 0.f : -sc * v.y;
+                pf[2 * K] = sc * u.x; pf[2 * K + 1] = edge ? T(0) : sc * u.y;
+                pf[2 * (M - K)] = sc * v.x; pf[2 * (M - K) + 1] = edge ? T(0) : -sc * v.y;
             }
-            if (own0) { pf[M] = 2.0f * sc * zmid.x; pf[M + 1] = -2.0f * sc * zmid.y; }
+            if (own0) { pf[M] = T(2) * sc * zmid.x; pf[M + 1] = T(-2) * sc * zmid.y; }
             wave_sync();
             R512X_STAMP(5);
         } else {
-            float pw[16];                                      // pw[k2] = P[K], pw[8 + k2] = P[M - K]
-            float pmid = 4.0f * cx_norm<float>(zz[slot16(8)]); // K = M / 2: lane j == 0 of group 0 only
+            T pw[16];                                          // pw[k2] = P[K], pw[8 + k2] = P[M - K]
+            T pmid = T(4) * cx_norm<T>(zz[slot16(8)]);         // K = M / 2: lane j == 0 of group 0 only
 #pragma unroll
             for (int k2 = 0; k2 < 8; ++k2) {
                 const C z = zz[slot16(k2)];
                 // (lane 0 of residue 0 is its own partner: the moves hand it its own register 15 - k2, which the last
                 // select replaces by register (16 - k2) % 16)
                 const C own = zz[slot16((16 - k2) & 15)], oth = zz[slot16(15 - k2)];
-                const float mx1 = r512x_mirror(oth.x), my1 = r512x_mirror(oth.y);
-                const float mx2 = r512x_ror1(mx1), my2 = r512x_ror1(my1);
+                const T mx1 = r512x_mirror(oth.x), my1 = r512x_mirror(oth.y);
+                const T mx2 = r512x_ror1(mx1), my2 = r512x_ror1(my1);
                 C m;
                 if constexpr (Q == 2) {
                     m = C{r == 0 ? mx2 : mx1, r == 0 ? my2 : my1};
                 } else {
-                    const float mx3 = r512x_xor32(mx1, lane < 32), my3 = r512x_xor32(my1, lane < 32);
+                    const T mx3 = r512x_xor32(mx1, lane < 32), my3 = r512x_xor32(my1, lane < 32);
                     m = C{r == 0 ? mx2 : (r == 2 ? mx1 : mx3), r == 0 ? my2 : (r == 2 ? my1 : my3)};
                 }
                 m = C{own0 ? own.x : m.x, own0 ? own.y : m.y};
-                const C A = cx_add_conj<float>(z, m), B = cx_sub_conj<float>(z, m);
-                const C Tw = cx_mul<float>(B, ow[k2]);
-                pw[k2] = cx_norm<float>(A + Tw);
-                pw[8 + k2] = cx_norm<float>(A - Tw);
+                const C A = cx_add_conj<T>(z, m), B = cx_sub_conj<T>(z, m);
+                const C Tw = cx_mul<T>(B, ow[k2]);
+                pw[k2] = cx_norm<T>(A + Tw);
+                pw[8 + k2] = cx_norm<T>(A - Tw);
             }
             if (EPI) {
                 power_epilogue_n(pw, a.epi);
@@ -438,7 +474,7 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
             wave_sync();                                       // every lane has read its tile row: reuse the region
             R512X_STAMP(5);                                    // split
             {
-                float *pf = xs + sh + f * F;
+                T *pf = xs + sh + f * F;
 #pragma unroll
                 for (int k2 = 0; k2 < 8; ++k2) {
                     const int K = Q * (j + 16 * k2) + r;
@@ -453,7 +489,16 @@ __global__ __launch_bounds__(64 * R512X_WAVES, 2) void stft_r512x_kernel(float *
         // ---- five stores: four of whole 16-byte vectors, one for the values before and after them.  Surplus
         // lanes repeat a valid store (same value to the same address).
         R512X_STAMP(6);                                    // staging
-        ring_store_rows<NVI, R512X_NOSTORE != 0>(yblk, xs + sh, head, nout, lane);
+        if constexpr (F32) {
+            ring_store_rows<NVI, R512X_NOSTORE != 0>(yblk, xs + sh, head, nout, lane);
+        } else {
+            // float64: element-wise, a wave stores 512 consecutive bytes per instruction, at any 8-byte alignment
+#pragma unroll
+            for (int i = 0; i < NSTORE; ++i) {
+                const int e = min(lane + 64 * i, nout - 1);
+                __builtin_nontemporal_store(xs[e], yblk + e);
+            }
+        }
         R512X_STAMP(7);                                    // stores issued
         if (!more) { break; }
         wave_sync();                                       // staging reads are done before the next step writes the tile
@@ -490,24 +535,25 @@ bool r512x_supported(const FrameDesc &d)
            d.ss0 > -(1ll << 30) && d.ss0 < (1ll << 30) && d.rd_shift >= 0 && d.rd_shift < (1ll << 30);
 }
 
-template <int Q, bool FULL, bool MN0, bool EPI, int SPAN, bool ALN, bool CPLX = false>
-static hipError_t launch_r512x_inst(float *Y, const float *X, const float *win, const float *tw, const R512XArgs &a, hipStream_t s)
+template <typename T, int Q, bool FULL, bool MN0, bool EPI, int SPAN, bool ALN, bool CPLX = false>
+static hipError_t launch_r512x_inst(T *Y, const T *X, const T *win, const T *tw, const R512XArgs &a, hipStream_t s)
 {
-    const size_t lds = ((size_t)R512X_WAVES * (R512X_TILE + SPAN) + (R512X_TWD_LDS ? 512 : 0) + 256) * sizeof(float) + 16;
+    constexpr int NWV = r512x_waves<T>();
+    const size_t lds = ((size_t)NWV * (R512X_TILE + SPAN) + (R512X_TWD_LDS ? 512 : 0)) * sizeof(T) + 1024 + 16;
     static LdsGrant grant;
-    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r512x_kernel<Q, FULL, MN0, EPI, SPAN, ALN, CPLX>), lds, grant); e != hipSuccess) { return e; }
-    long long grid = ((long long)a.steps + R512X_WAVES - 1) / R512X_WAVES;
-    if (grid > 256) { grid = 256; }                     // one 8-wave workgroup per CU
+    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r512x_kernel<T, Q, FULL, MN0, EPI, SPAN, ALN, CPLX>), lds, grant); e != hipSuccess) { return e; }
+    long long grid = ((long long)a.steps + NWV - 1) / NWV;
+    if (grid > 256) { grid = 256; }                     // one workgroup per CU
     grid = (grid + 7) & ~7ll;                           // whole groups of 8 workgroups (one per XCD)
-    hipLaunchKernelGGL((stft_r512x_kernel<Q, FULL, MN0, EPI, SPAN, ALN, CPLX>), dim3((unsigned)grid), dim3(64 * R512X_WAVES), lds, s, Y, X, win, tw, a);
+    hipLaunchKernelGGL((stft_r512x_kernel<T, Q, FULL, MN0, EPI, SPAN, ALN, CPLX>), dim3((unsigned)grid), dim3(64 * NWV), lds, s, Y, X, win, tw, a);
     return hipGetLastError();
 }
 
-template <int Q, int SPAN, bool ALN>
-static hipError_t launch_r512x_shape(float *Y, const float *X, const float *win, const float *tw, const R512XArgs &a, const FrameDesc &d, hipStream_t s)
+template <typename T, int Q, int SPAN, bool ALN>
+static hipError_t launch_r512x_shape(T *Y, const T *X, const T *win, const T *tw, const R512XArgs &a, const FrameDesc &d, hipStream_t s)
 {
     const bool full = d.L == d.nfft, epi = d.epi.any();
-#define DSP_R512X(F_, M_, E_) launch_r512x_inst<Q, F_, M_, E_, SPAN, ALN>(Y, X, win, tw, a, s)
+#define DSP_R512X(F_, M_, E_) launch_r512x_inst<T, Q, F_, M_, E_, SPAN, ALN>(Y, X, win, tw, a, s)
 #if R512X_MINIMAL
     if (full && !d.mn0 && !epi) { return DSP_R512X(true, false, false); }
     return hipErrorInvalidValue;
@@ -522,7 +568,8 @@ static hipError_t launch_r512x_shape(float *Y, const float *X, const float *win,
 #undef DSP_R512X
 }
 
-hipError_t launch_stft_r512x(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, hipStream_t s)
+template <typename T>
+static hipError_t launch_r512x_any(T *Y, const T *X, const T *win, const T *tw, const FrameDesc &d, hipStream_t s)
 {
     const int Q = d.nfft / 512, fps = 4 / Q;
     R512XArgs a{};
@@ -532,10 +579,18 @@ hipError_t launch_stft_r512x(float *Y, const float *X, const float *win, const f
     a.steps = d.B * a.sps;
     a.tbl = d.tbl; a.reach = 0;
     if (d.tbl) { a.stp = 0; a.ss0 = 0; a.rd_shift = 0; a.reach = (fps == 1) ? 0 : d.tbl_reach; }
-    if (Q == 4) { return launch_r512x_shape<4, 2048, true>(Y, X, win, tw, a, d, s); }
-    if (d.tbl || (d.stp & 1)) { return launch_r512x_shape<2, 2048, false>(Y, X, win, tw, a, d, s); }
-    if (d.stp + 1024 <= 1280) { return launch_r512x_shape<2, 1280, true>(Y, X, win, tw, a, d, s); }
-    return launch_r512x_shape<2, 2048, true>(Y, X, win, tw, a, d, s);
+    if (Q == 4) { return launch_r512x_shape<T, 4, 2048, true>(Y, X, win, tw, a, d, s); }
+    if (d.tbl || (d.stp & 1)) { return launch_r512x_shape<T, 2, 2048, false>(Y, X, win, tw, a, d, s); }
+    if (d.stp + 1024 <= 1280) { return launch_r512x_shape<T, 2, 1280, true>(Y, X, win, tw, a, d, s); }
+    return launch_r512x_shape<T, 2, 2048, true>(Y, X, win, tw, a, d, s);
+}
+hipError_t launch_stft_r512x(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, hipStream_t s)
+{
+    return launch_r512x_any<float>(Y, X, win, tw, d, s);
+}
+hipError_t launch_stft_r512x(double *Y, const double *X, const double *win, const double *tw, const FrameDesc &d, hipStream_t s)
+{
+    return launch_r512x_any<double>(Y, X, win, tw, d, s);
 }
 
 // The complex form: Y[b][w][nfft/2+1] interleaved (re, im) pairs times `scale`; equally spaced frames, no mean removal.
@@ -550,8 +605,8 @@ static hipError_t launch_r512x_cplx_shape(float *Y, const float *X, const float 
 #if R512X_MINIMAL
     return hipErrorInvalidValue;
 #else
-    if (d.L == d.nfft) { return launch_r512x_inst<Q, true, false, false, SPAN, ALN, true>(Y, X, win, tw, a, s); }
-    return launch_r512x_inst<Q, false, false, false, SPAN, ALN, true>(Y, X, win, tw, a, s);
+    if (d.L == d.nfft) { return launch_r512x_inst<float, Q, true, false, false, SPAN, ALN, true>(Y, X, win, tw, a, s); }
+    return launch_r512x_inst<float, Q, false, false, false, SPAN, ALN, true>(Y, X, win, tw, a, s);
 #endif
 }
 
@@ -564,7 +619,7 @@ hipError_t launch_stft_r512x_cplx(float *Y, const float *X, const float *win, co
     a.sps = (d.W + fps - 1) / fps;
     a.steps = d.B * a.sps;
     a.tbl = nullptr; a.reach = 0;
-    a.cscale = (float)scale;
+    a.cscale = scale;
     if (Q == 4) { return launch_r512x_cplx_shape<4, 2048, true>(Y, X, win, tw, a, d, s); }
     if (d.stp & 1) { return launch_r512x_cplx_shape<2, 2048, false>(Y, X, win, tw, a, d, s); }
     if (d.stp + 1024 <= 1280) { return launch_r512x_cplx_shape<2, 1280, true>(Y, X, win, tw, a, d, s); }

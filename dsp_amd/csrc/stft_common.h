@@ -222,6 +222,7 @@ hipError_t launch_stft_r4096(float *Y, const float *X, const float *win, const f
 // nfft 1024 and 2048, float32, equally spaced frames (r512x_kernel.hip)
 bool r512x_supported(const FrameDesc &d);
 hipError_t launch_stft_r512x(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, hipStream_t s);
+hipError_t launch_stft_r512x(double *Y, const double *X, const double *win, const double *tw, const FrameDesc &d, hipStream_t s);   // 4 waves per workgroup
 // nfft 256, 128 and 64 (r256_kernel.hip)
 bool r256_supported(const FrameDesc &d);
 hipError_t launch_stft_r256(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, hipStream_t s);

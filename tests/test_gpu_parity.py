@@ -162,7 +162,7 @@ def test_256_1024_2048_kernels_agree_with_oracle(O, D):
     rules, and outputs that start 4, 8 and 12 bytes off a 16-byte boundary."""
     import torch
     dt = np.float32
-    assert D.kernel_family(1024, dt) == 6 and D.kernel_family(2048, dt) == 6 and D.kernel_family(1024, np.float64) == 5
+    assert D.kernel_family(1024, dt) == 6 and D.kernel_family(2048, dt) == 6
     assert D.kernel_family(256, dt) == 7 and D.kernel_family(128, dt) == 7 and D.kernel_family(64, dt) == 7 and D.kernel_family(32, dt) == 5
     shapes = [(128, 128, 32, (0, 0, 0)), (128, 100, 40, (1, 0, 0)), (128, 127, 17, (0, 1, 0)), (128, 65, 128, (1, 1, 1)), (128, 104, 73, (0, 0, 1)),
               (128, 97, 129, (0, 0, 0)), (128, 2, 1, (1, 0, 0)), (128, 128, 64, (0, 0, 0)),
@@ -240,7 +240,7 @@ def test_64_128_256_kernels_float64(O, D):
     bytes around them untouched, bit-equal repeats on a full grid, stft_flt with whole and fractional hops in both framings."""
     import torch
     dt = np.float64
-    assert D.kernel_family(256, dt) == 7 and D.kernel_family(128, dt) == 7 and D.kernel_family(64, dt) == 7 and D.kernel_family(1024, dt) == 5
+    assert D.kernel_family(256, dt) == 7 and D.kernel_family(128, dt) == 7 and D.kernel_family(64, dt) == 7 and D.kernel_family(32, dt) == 5
     shapes = [(256, 256, 64, (0, 0, 0)), (256, 200, 80, (1, 0, 0)), (256, 255, 33, (0, 1, 0)), (256, 129, 256, (1, 1, 1)), (256, 208, 146, (0, 0, 1)),
               (256, 193, 257, (0, 0, 0)), (256, 2, 1, (1, 0, 0)),
               (128, 128, 32, (0, 0, 0)), (128, 100, 40, (1, 0, 0)), (128, 127, 17, (0, 1, 0)), (128, 65, 128, (1, 1, 1)), (128, 104, 73, (0, 0, 1)),
@@ -290,6 +290,67 @@ def test_64_128_256_kernels_float64(O, D):
                 for (c0, stp, W) in [(0.0, nfft / 4.0, 75), (-3.0 * nfft, nfft / 2.0, 41), (100.0, nfft / 4.0 + 0.5, 67), (29000.0, nfft / 4.0 + 0.25, 70),
                                      (700.0, 300.0, 40)]:
                     rc, Yref = O.stft_flt(x, win, W, c0, stp, nfft, 0, 0, 0, intended=intended)
+                    assert rc == 0
+                    Y = D.stft_flt(x, win, W, c0, stp, nfft=nfft)
+                    check_spec(O, Y, Yref)
+            finally:
+                D.set_flt_mode(False)
+
+
+def test_1024_2048_kernels_float64(O, D):
+    """The float64 form of the nfft 1024 / 2048 kernel (family 6; 4 waves per workgroup, lane moves in two halves, rows
+    stored element by element): the shapes of the float32 test (full, short and odd windows, hops of every alignment up to
+    the span limit and past it, every flag, both edge rules, a signal shorter than the window), outputs at both 8-byte
+    alignments with the bytes around them untouched, bit-equal repeats on a full grid, stft_flt in both framings."""
+    import torch
+    dt = np.float64
+    assert D.kernel_family(1024, dt) == 6 and D.kernel_family(2048, dt) == 6 and D.kernel_family(4096, dt) == 5
+    shapes = [(1024, 1024, 256, (0, 0, 0)), (1024, 1024, 255, (1, 0, 0)), (1024, 800, 200, (0, 1, 0)), (1024, 513, 1024, (1, 1, 1)),
+              (1024, 1000, 1025, (0, 0, 0)), (1024, 3, 77, (1, 0, 1)), (1024, 1024, 1, (0, 0, 0)), (1024, 1024, 128, (0, 0, 1)),
+              (2048, 2048, 512, (0, 0, 0)), (2048, 2047, 441, (1, 0, 0)), (2048, 1200, 300, (0, 1, 1)), (2048, 1025, 5000, (1, 1, 0)),
+              (2048, 2048, 1, (0, 0, 1))]
+    for (nfft, L, stp, flags) in shapes:
+        for N in ((12 * nfft + 77) if stp > 1 else nfft + 300, L // 2 + 1):
+            x = signal(nfft + N + stp, N, dt) + dt(0.15)
+            win = D.povey(L, dt)
+            for snip in (0, 1):
+                if snip and L > N:
+                    continue
+                rc, Yref = O.stft(x, win, stp, nfft, snip, *flags, exact=False)
+                assert rc == 0
+                Y = D.stft(x, win, stp, bool(snip), *[bool(f) for f in flags], nfft=nfft)
+                check_spec(O, Y, Yref, flags[1], flags[2])
+    for (nfft, stp, N) in [(1024, 256, 9000), (1024, 300, 9301), (2048, 512, 20000)]:
+        xs = np.stack([signal(10 * k + nfft, N, dt) for k in range(3)])
+        win = D.hann(nfft, dt)
+        want = np.stack([O.stft(r, win, stp, nfft, 0, exact=False)[1] for r in xs])
+        xd, wd = torch.from_numpy(xs).cuda(), torch.from_numpy(win).cuda()
+        for off in (0, 1):
+            buf = torch.full((want.size + 4,), 7.0, dtype=torch.float64, device="cuda")
+            out = buf[off:off + want.size].view(want.shape)
+            D.stft_dev(xd, wd, stp, nfft=nfft, out=out)
+            torch.cuda.synchronize()
+            check_spec(O, out.cpu().numpy(), want)
+            assert float(buf[:off].sum()) == 7.0 * off and bool((buf[off + want.size:] == 7.0).all())
+    for (nfft, stp) in [(1024, 256), (2048, 512)]:
+        xd = torch.randn((64, 1 << 19), device="cuda", dtype=torch.float64, generator=torch.Generator(device="cuda").manual_seed(nfft))
+        wd = torch.from_numpy(D.hann(nfft, dt)).cuda()
+        y0 = D.stft_dev(xd, wd, stp, nfft=nfft)
+        y1 = torch.empty_like(y0)
+        for _ in range(5):
+            D.stft_dev(xd, wd, stp, nfft=nfft, out=y1)
+            assert torch.equal(y0, y1)
+        alone = D.stft_dev(xd[37:38].clone(), wd, stp, nfft=nfft)
+        assert torch.equal(alone[0], y0[37])
+        del xd, y0, y1
+    x = signal(78, 30000, dt)
+    for nfft in (1024, 2048):
+        win = D.blackmanharris(nfft, dt)
+        for intended in (False, True):
+            D.set_flt_mode(intended)
+            try:
+                for (c0, stp, W) in [(0.0, 256.0, 31), (700.0, 300.0, 40), (-1500.0, 512.0, 20), (100.0, 250.5, 20), (100.0, nfft / 4.0 + 0.5, 67)]:
+                    rc, Yref = O.stft_flt(x, win, W, c0, stp, nfft, 0, 0, 0, intended=intended, exact=False)
                     assert rc == 0
                     Y = D.stft_flt(x, win, W, c0, stp, nfft=nfft)
                     check_spec(O, Y, Yref)

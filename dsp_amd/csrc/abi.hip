@@ -1265,20 +1265,20 @@ int stft_cplx_dev(const char *fn, T *Yd, const T *Xd, const T *wd, size_t B, siz
         HIPCHK(fn, launch_stft_r512_fast_cplx<T>(Yd, Xd, wd, tw, d, scale, s));
         return 0;
     }
+    if ((nfft == 1024 || nfft == 2048) && !tl_force_generic && r512x_cplx_supported(d)) {
+        if (get_twiddles<T>(fn, dev, nfft, 0, tw)) { return 1; }
+        HIPCHK(fn, launch_stft_r512x_cplx(Yd, Xd, wd, tw, d, scale, s));
+        return 0;
+    }
+    if ((nfft == 256 || nfft == 128 || nfft == 64) && !tl_force_generic && r256_cplx_supported(d)) {
+        if (get_twiddles<T>(fn, dev, nfft, 0, tw)) { return 1; }
+        HIPCHK(fn, launch_stft_r256_cplx(Yd, Xd, wd, tw, d, scale, s));
+        return 0;
+    }
     if constexpr (sizeof(T) == 4) {
-        if ((nfft == 1024 || nfft == 2048) && !tl_force_generic && r512x_cplx_supported(d)) {
-            if (get_twiddles<T>(fn, dev, nfft, 0, tw)) { return 1; }
-            HIPCHK(fn, launch_stft_r512x_cplx(Yd, Xd, wd, tw, d, scale, s));
-            return 0;
-        }
         if (nfft == 4096 && !tl_force_generic && r4096_cplx_supported(d)) {
             if (get_twiddles<T>(fn, dev, nfft, 0, tw)) { return 1; }
             HIPCHK(fn, launch_stft_r4096_cplx(Yd, Xd, wd, tw, d, scale, s));
-            return 0;
-        }
-        if ((nfft == 256 || nfft == 128 || nfft == 64) && !tl_force_generic && r256_cplx_supported(d)) {
-            if (get_twiddles<T>(fn, dev, nfft, 0, tw)) { return 1; }
-            HIPCHK(fn, launch_stft_r256_cplx(Yd, Xd, wd, tw, d, scale, s));
             return 0;
         }
     }

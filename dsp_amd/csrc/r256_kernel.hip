@@ -442,11 +442,7 @@ template <typename T, int CL, int NR, int SPAN, bool ALN>
 static hipError_t launch_r256_shape(T *Y, const T *X, const T *win, const T *tw, const R256Args &a, const FrameDesc &d, bool cplx, hipStream_t s)
 {
     const bool epi = d.epi.any();
-    if constexpr (sizeof(T) == 4) {
-        if (cplx) { return launch_r256_inst<T, CL, NR, false, false, SPAN, ALN, true>(Y, X, win, tw, a, s); }
-    } else {
-        if (cplx) { return hipErrorInvalidValue; }      // (the complex form exists in float32 only)
-    }
+    if (cplx) { return launch_r256_inst<T, CL, NR, false, false, SPAN, ALN, true>(Y, X, win, tw, a, s); }
 #if R256_MINIMAL
     if (!d.mn0 && !epi) { return launch_r256_inst<T, CL, NR, false, false, SPAN, ALN>(Y, X, win, tw, a, s); }
     return hipErrorInvalidValue;
@@ -513,6 +509,10 @@ bool r256_cplx_supported(const FrameDesc &d)
 hipError_t launch_stft_r256_cplx(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, double scale, hipStream_t s)
 {
     return launch_r256_any<float>(Y, X, win, tw, d, true, scale, s);
+}
+hipError_t launch_stft_r256_cplx(double *Y, const double *X, const double *win, const double *tw, const FrameDesc &d, double scale, hipStream_t s)
+{
+    return launch_r256_any<double>(Y, X, win, tw, d, true, scale, s);
 }
 
 }  // namespace dsp

@@ -599,18 +599,19 @@ bool r512x_cplx_supported(const FrameDesc &d)
     return r512x_supported(d) && d.tbl == nullptr && !d.mn0 && !d.epi.any() && (long long)d.wy() * (d.nfft + 2) < (1ll << 30);
 }
 
-template <int Q, int SPAN, bool ALN>
-static hipError_t launch_r512x_cplx_shape(float *Y, const float *X, const float *win, const float *tw, const R512XArgs &a, const FrameDesc &d, hipStream_t s)
+template <typename T, int Q, int SPAN, bool ALN>
+static hipError_t launch_r512x_cplx_shape(T *Y, const T *X, const T *win, const T *tw, const R512XArgs &a, const FrameDesc &d, hipStream_t s)
 {
 #if R512X_MINIMAL
     return hipErrorInvalidValue;
 #else
-    if (d.L == d.nfft) { return launch_r512x_inst<float, Q, true, false, false, SPAN, ALN, true>(Y, X, win, tw, a, s); }
-    return launch_r512x_inst<float, Q, false, false, false, SPAN, ALN, true>(Y, X, win, tw, a, s);
+    if (d.L == d.nfft) { return launch_r512x_inst<T, Q, true, false, false, SPAN, ALN, true>(Y, X, win, tw, a, s); }
+    return launch_r512x_inst<T, Q, false, false, false, SPAN, ALN, true>(Y, X, win, tw, a, s);
 #endif
 }
 
-hipError_t launch_stft_r512x_cplx(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, double scale, hipStream_t s)
+template <typename T>
+static hipError_t launch_r512x_cplx_any(T *Y, const T *X, const T *win, const T *tw, const FrameDesc &d, double scale, hipStream_t s)
 {
     const int Q = d.nfft / 512, fps = 4 / Q;
     R512XArgs a{};
@@ -620,10 +621,18 @@ hipError_t launch_stft_r512x_cplx(float *Y, const float *X, const float *win, co
     a.steps = d.B * a.sps;
     a.tbl = nullptr; a.reach = 0;
     a.cscale = scale;
-    if (Q == 4) { return launch_r512x_cplx_shape<4, 2048, true>(Y, X, win, tw, a, d, s); }
-    if (d.stp & 1) { return launch_r512x_cplx_shape<2, 2048, false>(Y, X, win, tw, a, d, s); }
-    if (d.stp + 1024 <= 1280) { return launch_r512x_cplx_shape<2, 1280, true>(Y, X, win, tw, a, d, s); }
-    return launch_r512x_cplx_shape<2, 2048, true>(Y, X, win, tw, a, d, s);
+    if (Q == 4) { return launch_r512x_cplx_shape<T, 4, 2048, true>(Y, X, win, tw, a, d, s); }
+    if (d.stp & 1) { return launch_r512x_cplx_shape<T, 2, 2048, false>(Y, X, win, tw, a, d, s); }
+    if (d.stp + 1024 <= 1280) { return launch_r512x_cplx_shape<T, 2, 1280, true>(Y, X, win, tw, a, d, s); }
+    return launch_r512x_cplx_shape<T, 2, 2048, true>(Y, X, win, tw, a, d, s);
+}
+hipError_t launch_stft_r512x_cplx(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, double scale, hipStream_t s)
+{
+    return launch_r512x_cplx_any<float>(Y, X, win, tw, d, scale, s);
+}
+hipError_t launch_stft_r512x_cplx(double *Y, const double *X, const double *win, const double *tw, const FrameDesc &d, double scale, hipStream_t s)
+{
+    return launch_r512x_cplx_any<double>(Y, X, win, tw, d, scale, s);
 }
 
 }  // namespace dsp

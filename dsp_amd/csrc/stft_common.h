@@ -236,7 +236,9 @@ bool r256_cplx_supported(const FrameDesc &d);
 bool r4096_cplx_supported(const FrameDesc &d);
 hipError_t launch_stft_r4096_cplx(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, double scale, hipStream_t s);
 hipError_t launch_stft_r256_cplx(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, double scale, hipStream_t s);
+hipError_t launch_stft_r256_cplx(double *Y, const double *X, const double *win, const double *tw, const FrameDesc &d, double scale, hipStream_t s);
 hipError_t launch_stft_r512x_cplx(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, double scale, hipStream_t s);
+hipError_t launch_stft_r512x_cplx(double *Y, const double *X, const double *win, const double *tw, const FrameDesc &d, double scale, hipStream_t s);
 template <typename T> hipError_t launch_stft_r512_fast_cplx(T *Y, const T *X, const T *win, const T *tw, const FrameDesc &d, double scale, hipStream_t s);
 
 // ---- unfused kernels (unfused_kernels.hip) ----------------------------------------------------

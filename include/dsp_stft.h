@@ -241,7 +241,7 @@ int dsp_stft_flt_batch_dev_strided_d (double *Y_dev, const double *X_dev, const 
 /* The complex spectrogram of B signals: the frames of stft (same W, same edge reflection) times the window, then the
  * real FFT of each as fft_fftw_r2hc_s/_d returns it: Y[b][w][F] interleaved (re, im) pairs, F = nfft/2+1, the imaginary
  * parts of bins 0 and nfft/2 zero; sc != 0 scales by 1/sqrt(2 nfft) (reference c/window_univar.c:41-89 followed by
- * c/fft.fftw.r2hc.c:24-109 along the frames, fused).  nfft 512 with hop <= 512 and float32 nfft 64 / 128 / 256 / 1024 / 2048 / 4096 run on the
+ * c/fft.fftw.r2hc.c:24-109 along the frames, fused).  nfft 64 / 128 / 256 / 512 / 1024 / 2048 (and float32 nfft 4096) run on the
  * fused kernels (the rows leave as complex values instead of powers), anything else on the unfused kernels. */
 int dsp_stft_cplx_batch_dev_s (float *Y_dev, const float *X_dev, const float *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int sc, void *stream);
 int dsp_stft_cplx_batch_dev_d (double *Y_dev, const double *X_dev, const double *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int sc, void *stream);

@@ -1508,7 +1508,7 @@ def test_complex_spectrogram(O, D, dt):
     by fft_fftw_r2hc gives, c/window_univar.c:41-89, c/fft.fftw.r2hc.c:69-78), against the oracle's framing and r2hc
     restatements applied one after the other; its squared magnitude equals the power spectrogram of stft on the same
     input.  Shapes of the fused 512-point kernel (all span forms, odd hop, 13- and 16-row windows, blocks of rows off
-    16-byte boundaries, a batch), of the 1024 / 2048-point kernel (float32) and of the unfused fallback (other nfft, hop
+    16-byte boundaries, a batch), of the 64 / 128 / 256- and 1024 / 2048-point kernels and of the unfused fallback (other nfft, hop
     above 512, a transform length that is no power of two); the 1/sqrt(2 nfft) scaling."""
     import torch
     tol = TOL[np.dtype(dt)]
@@ -1516,10 +1516,10 @@ def test_complex_spectrogram(O, D, dt):
     cases = [(3, 16000, 400, 160, 512, False), (2, 16001, 400, 161, 512, False), (2, 9000, 512, 256, 512, False), (1, 20000, 300, 400, 512, True),
              (2, 7000, 400, 200, 512, False), (1, 5000, 512, 128, 512, False), (5, 1603, 400, 160, 512, False),
              (2, 6000, 256, 64, 256, False), (1, 9000, 1024, 256, 1024, False), (1, 9000, 400, 600, 512, False), (2, 3000, 100, 50, 120, False),
-             # the 1024 / 2048-point kernel's complex form (float32; float64 takes the unfused kernels)
+             # the 1024 / 2048-point kernel's complex form
              (2, 20000, 800, 200, 1024, False), (3, 9000, 1024, 512, 1024, True), (2, 30000, 2048, 512, 2048, False), (2, 12001, 1200, 301, 2048, False),
              (1, 9001, 1024, 255, 1024, False), (5, 4099, 2048, 1024, 2048, False),
-             # the 256-point kernel's (float32)
+             # the 256-point kernel's
              (3, 8000, 200, 80, 256, False), (2, 8001, 256, 81, 256, True), (4, 3001, 256, 128, 256, False), (1, 9000, 130, 200, 256, False),
              # the 128- and 64-point forms of that kernel
              (3, 8000, 100, 40, 128, False), (2, 8001, 128, 41, 128, True), (4, 3001, 128, 64, 128, False), (1, 9000, 70, 128, 128, False),

@@ -306,7 +306,7 @@ int dsp_fft_power_dev_z (double *Y_dev, const double *X_dev, const size_t N, voi
 /* Which kernel family the fused path would use for (nfft, element size 4 or 8):
  * 0 = none (invalid), 1 = direct DFT (nfft not a power of two), 2 = generic power-of-two,
  * 3 = register-resident 512-point, 4 = register-resident 4096-point (float32), 5 = the other powers of two from 16
- * to 8192 (float32) / 4096 (float64), 6 = 1024- and 2048-point (float32), 7 = 64-, 128- and 256-point.  Families 6 and 7
+ * to 8192 (float32) / 4096 (float64), 6 = 1024- and 2048-point, 7 = 64-, 128- and 256-point.  Families 6 and 7
  * take frames (equally spaced, or the stft_flt framing of any hop) that keep a step (2, 1 and 8 frames) inside 2048
  * samples; other framings of those lengths run on family 5.  For tests and benchmarks. */
 int dsp_stft_kernel_family (const size_t nfft, const size_t elem_size);

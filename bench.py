@@ -45,11 +45,11 @@ WORKLOADS = {
     "utt1x10s_f32_hann400_hop160_nfft512": ("float32", 1, 160000, "hann", 400, 160, 512, "stft"),
     "flt_f64_8ch_x_1h16k_povey400_hop160_nfft512": ("float64", 8, 57600000, "povey", 400, 160, 512, "flt"),
     "longwin_f32_8ch_x_1h48k_bh4096_hop1024_nfft4096": ("float32", 8, 172800000, "blackmanharris", 4096, 1024, 4096, "stft"),
-    # configurations 3 and 4 of BASELINE.json as single launches: all 64 float64 channels (29.5 GB in, 47.4 GB out) and
+    # the 64-channel forms of the long-signal workloads as single launches: all 64 float64 channels (29.5 GB in, 47.4 GB out) and
     # 32 of the 128 float32 channels (22.1 GB in, 44.3 GB out; all 128 are 265 GB and do not fit one GPU beside anything else)
     "flt_f64_64ch_x_1h16k_povey400_hop160_nfft512": ("float64", 64, 57600000, "povey", 400, 160, 512, "flt"),
     "longwin_f32_32ch_x_1h48k_bh4096_hop1024_nfft4096": ("float32", 32, 172800000, "blackmanharris", 4096, 1024, 4096, "stft"),
-    # the other transform lengths with kernels of their own (not configurations of BASELINE.json)
+    # the other transform lengths with kernels of their own (not headline configurations)
     "tel1024x10s8k_f32_hann200_hop80_nfft256": ("float32", 1024, 80000, "hann", 200, 80, 256, "stft"),
     "music64x60s44k_f32_hann1024_hop256_nfft1024": ("float32", 64, 2646000, "hann", 1024, 256, 1024, "stft"),
     "music64x60s44k_f32_hann2048_hop512_nfft2048": ("float32", 64, 2646000, "hann", 2048, 512, 2048, "stft"),

@@ -1,12 +1,19 @@
 """Seeded random shapes through every kernel family against the oracle: transform lengths from 16 to 8192,
 any window length up to nfft, any hop (odd, above the window, above the span limits), signals shorter than a
 window, every flag, snipped edges, and stft_flt with integral and fractional hops in both framing modes."""
+import os
+
 import numpy as np
 import pytest
 
 from test_gpu_parity import check_spec, signal
 
 pytestmark = pytest.mark.gpu
+
+# DSP_FUZZ_SEED shifts the seeds, DSP_FUZZ_SCALE multiplies the number of shapes (longer runs by hand; the defaults are
+# what the suite runs)
+SEED = int(os.environ.get("DSP_FUZZ_SEED", "0"))
+SCALE = int(os.environ.get("DSP_FUZZ_SCALE", "1"))
 
 
 @pytest.fixture(scope="module")
@@ -17,8 +24,8 @@ def D():
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 def test_random_shapes_stft(O, D, dt):
-    rng = np.random.default_rng(20240 + np.dtype(dt).itemsize)
-    for it in range(600):
+    rng = np.random.default_rng(20240 + np.dtype(dt).itemsize + 1000 * SEED)
+    for it in range(600 * SCALE):
         nfft = int(2 ** rng.integers(4, 14))
         L = int(rng.integers(1, nfft + 1)) if rng.random() < 0.6 else nfft
         stp = int(rng.integers(1, 2 * L + 2)) if rng.random() < 0.7 else max(1, L // int(rng.integers(2, 6)))
@@ -51,8 +58,8 @@ def test_random_shapes_stft(O, D, dt):
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 def test_random_shapes_stft_flt(O, D, dt):
-    rng = np.random.default_rng(777 + np.dtype(dt).itemsize)
-    for it in range(400):
+    rng = np.random.default_rng(777 + np.dtype(dt).itemsize + 1000 * SEED)
+    for it in range(400 * SCALE):
         nfft = int(2 ** rng.integers(4, 14))
         L = int(rng.integers(1, nfft + 1)) if rng.random() < 0.6 else nfft
         N = int(rng.integers(L + 1, 10 * L + 60))

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from test_gpu_parity import check_spec, signal
+from test_gpu_parity import TOL, check_spec, signal
 
 pytestmark = pytest.mark.gpu
 
@@ -93,3 +93,42 @@ def test_random_shapes_stft_flt(O, D, dt):
                     raise AssertionError(f"nfft {nfft} L {L} stp {stp} N {N} W {W} c0 {c0} flags {flags} intended {intended} generic {generic}: {e}")
         finally:
             D.set_flt_mode(False)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_random_large_shapes_fast_kernels_against_generic(O, D, dt):
+    """The kernels with work distribution over the whole chip (drawn steps, ranges per XCD, span slots refilled step after
+    step) on inputs of many steps per wave: random batches of long signals, transform lengths 64 to 4096, window lengths,
+    hops inside and outside the span limits, flags, snipped edges; against the generic kernels (one workgroup per frame,
+    checked against the oracle by the tests above) on the same input, to the oracle's bound."""
+    import torch
+    rng = np.random.default_rng(4242 + np.dtype(dt).itemsize + 1000 * SEED)
+    tdt = torch.float32 if dt == np.float32 else torch.float64
+    g = torch.Generator(device="cuda").manual_seed(99 + SEED)
+    for it in range(40 * SCALE):
+        nfft = int(2 ** rng.integers(6, 13))
+        L = int(rng.integers(nfft // 2, nfft + 1)) if rng.random() < 0.5 else nfft
+        stp = int(rng.choice([nfft // 4, nfft // 2, nfft // 8 + 1, int(rng.integers(1, nfft + 2)), L]))
+        stp = max(stp, nfft // 64)
+        B = int(rng.integers(1, 6))
+        W = int(rng.integers(2000, 12000))
+        N = W * stp + int(rng.integers(0, L))
+        if B * N > 30_000_000:
+            N = 30_000_000 // B
+        snip = bool(rng.integers(0, 2)) and L <= N
+        flags = [bool(v) for v in rng.integers(0, 2, 3)]
+        x = torch.randn((B, N), device="cuda", dtype=tdt, generator=g) * 0.1 + 0.01
+        win = torch.from_numpy(D.povey(L, dt)).cuda()
+        Y = D.stft_dev(x, win, stp, snip, *flags, nfft=nfft)
+        D.force_generic(True)
+        try:
+            Yg = D.stft_dev(x, win, stp, snip, *flags, nfft=nfft)
+        finally:
+            D.force_generic(False)
+        torch.cuda.synchronize()
+        try:
+            for b in range(B):
+                check_spec(O, Y[b].cpu().numpy(), Yg[b].cpu().numpy(), int(flags[1]), int(flags[2]), tol=2 * TOL[np.dtype(dt)])   # (each side is within the bound of the oracle)
+        except AssertionError as e:
+            raise AssertionError(f"nfft {nfft} L {L} stp {stp} B {B} N {N} snip {snip} flags {flags}: {e}")
+        del x, Y, Yg

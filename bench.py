@@ -53,6 +53,9 @@ WORKLOADS = {
     "tel1024x10s8k_f32_hann200_hop80_nfft256": ("float32", 1024, 80000, "hann", 200, 80, 256, "stft"),
     "music64x60s44k_f32_hann1024_hop256_nfft1024": ("float32", 64, 2646000, "hann", 1024, 256, 1024, "stft"),
     "music64x60s44k_f32_hann2048_hop512_nfft2048": ("float32", 64, 2646000, "hann", 2048, 512, 2048, "stft"),
+    "tel1024x10s8k_f64_hann200_hop80_nfft256": ("float64", 1024, 80000, "hann", 200, 80, 256, "stft"),
+    "music64x60s44k_f64_hann1024_hop256_nfft1024": ("float64", 64, 2646000, "hann", 1024, 256, 1024, "stft"),
+    "music64x60s44k_f64_hann2048_hop512_nfft2048": ("float64", 64, 2646000, "hann", 2048, 512, 2048, "stft"),
 }
 DEFAULT_1GPU = "utt1024x10s_f32_hann400_hop160_nfft512"
 DEFAULT_NGPU = "utt8192x10s_f32_hann400_hop160_nfft512"

@@ -17,9 +17,11 @@
 //           the odd ones;
 //   exchange through LDS: 64 rows (k1, parity) of 32 values, pitch 33 (conflict-free both ways);
 //   pass 2  lane (k1, parity) runs one 32-point FFT and holds Z[k1 + 32 parity + 64 k'];
-//   split   Z goes to LDS once, each lane reads bins 4 lane + c + 256 m and 2048 minus those, and the
-//           real-FFT split is fused with the power step; 16-byte stores of 4 consecutive bins in both
-//           directions.
+//   split   the lanes are given their rows so that row r (lanes 0..31) and row 64 - r (lanes 32..63) sit 32
+//           lanes apart: of the pair Z[k], Z[2048 - k] that the real-FFT split needs, a lane holds Z[k] for
+//           k = r + 64 a, a < 16, itself and fetches the other from its partner's upper 16 values, which go
+//           through LDS once (8.5 KB per frame instead of the whole spectrum both ways); split and power
+//           in registers; a store instruction writes 64 consecutive bins, one per lane.
 // Two forms of the frame loop (template parameter RUN): with a full window and a hop of 1024 a wave
 // works through runs of 32 consecutive frames, loads every sample once and keeps the frame rotated in
 // its registers; otherwise frames are dealt round-robin inside 8 contiguous ranges (one per group of
@@ -66,9 +68,6 @@ typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));   // 16-
 #ifndef R4096_ABLATE
 #define R4096_ABLATE 0          // diagnostic builds: bit 0 = no row stores, bit 1 = no sample loads
 #endif
-#ifndef R4096_EARLY
-#define R4096_EARLY 8           // loads (of 16 per frame) issued before pass 2 instead of after it
-#endif
 #ifndef R4096_LOCKSTEP
 #define R4096_LOCKSTEP 1        // 1: the waves of a workgroup meet at a barrier every R4096_LOCK_EVERY frames
 #endif
@@ -94,20 +93,17 @@ typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));   // 16-
 #ifndef R4096_NT_STORE
 #define R4096_NT_STORE 0        // 1: rows are stored with the non-temporal hint
 #endif
-#ifndef R4096_WIN_AHEAD
-#define R4096_WIN_AHEAD 8       // run form: rows (of 16) of the next frame's window values that are read under the split of the current frame
-#endif
 #ifndef R4096_TA_AHEAD
 #define R4096_TA_AHEAD 1        // 1: run form reads the twiddle stage's per-lane factors right after the window step
 #endif
 #ifndef R4096_HACK
-#define R4096_HACK 0          // timing experiments only (wrong results): bit 0 = split without the constant factor, bit 1 = twiddle stage without the second factor, bit 2 = rows at a pitch of 2048 values and all stores on 16-byte boundaries
+#define R4096_HACK 0          // timing experiments only (wrong results): bit 0 = split without the constant factor, bit 1 = twiddle stage without the second factor
 #endif
 #ifndef R4096_STAMPS
 #define R4096_STAMPS 0          // diagnostic builds: 1 = per-phase s_memtime sums into g_r4096_stamps
 #endif
 #if R4096_STAMPS
-__device__ unsigned long long g_r4096_stamps[2048 * 8];
+__device__ unsigned long long g_r4096_stamps[2048 * 10];   // per wave: 8 phase sums, then the wave's whole life in shader cycles (s_memtime) and in ticks of the constant 100 MHz clock (s_memrealtime)
 #define R4096_STAMP(i)                                                                            \
     do {                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                        \
@@ -144,9 +140,10 @@ __device__ __forceinline__ void dft32c(C2 (&e)[16], C2 (&o)[16])
     }
 }
 
-// position of Z[k] in the wave's tile: the upper half of every 64-block is shifted by 8 inside
-// itself, which spreads the two half-blocks a wave store touches over all banks
-__device__ __forceinline__ int zpos(int k) { return k ^ (((k >> 5) & 1) << 3); }
+constexpr int R4096_X2P = 17;                           // second exchange: complex slots per lane (16 values + 1)
+// which instantiations keep the window in registers instead of LDS: the run form without mean removal, epilogue or
+// complex rows (those need the registers themselves)
+constexpr bool r4096_wreg(bool mn0, bool epi, bool run, bool cplx) { return run && !mn0 && !epi && !cplx; }
 
 template <int R> using rot = std::integral_constant<int, R>;
 
@@ -165,10 +162,16 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int L = a.L;
-    float *wtab = reinterpret_cast<float *>(smem_raw);                               // halved window, 4096 floats
-    C2 *ex = reinterpret_cast<C2 *>(wtab + 4096) + wv * R4096_WAVE_C;                 // this wave's tile
+    // The halved window, 4096 floats, in front of the tiles -- except in the plain run form (WREG), which has the
+    // registers to keep a lane's 64 window values for the whole launch.
+    constexpr bool WREG = r4096_wreg(MN0, EPI, RUN, CPLX);
+    float *wtab = reinterpret_cast<float *>(smem_raw);
+    C2 *tiles = reinterpret_cast<C2 *>(smem_raw) + (WREG ? 0 : 2048);
+    C2 *ex = tiles + wv * R4096_WAVE_C;                                               // this wave's tile
 
-    for (int l = tid; l < 4096; l += 64 * R4096_WAVES) { wtab[l] = (l < L) ? 0.5f * win[l] : 0.0f; }
+    if constexpr (!WREG) {
+        for (int l = tid; l < 4096; l += 64 * R4096_WAVES) { wtab[l] = (l < L) ? 0.5f * win[l] : 0.0f; }
+    }
 
     // Lane roles.  Loads: half-wave u takes the rows n1 = 2 i + u, lane l4 of it the complex columns
     // 2 l4 and 2 l4 + 1 (one 16-byte load per row).  After the 16-point transforms one swap between the
@@ -189,17 +192,21 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
 #pragma unroll
     for (int q = 1; q < 8; ++q) { ta[q] = tw2048(4 * n2 * q); }
     const C2 wl = C2{tw[2 * 64 * (n2 & 31)], tw[2 * 64 * (n2 & 31) + 1]};   // W64^(n2 % 32)
-    C2 owm[4];                                                            // -i W4096^(4 lane + c), for the split
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { owm[c] = C2{tw[2 * (4 * lane + c) + 1], -tw[2 * (4 * lane + c)]}; }
-    // RUN keeps a frame's raw samples in registers; the twiddles that depend on the lane alone and are
-    // used once per frame (ta, owm) then live in LDS, behind the tiles, and are read where they are used
-    C2 *twl = reinterpret_cast<C2 *>(wtab + 4096) + R4096_WAVES * R4096_WAVE_C;   // owm at [4 lane + c], ta[q] at [256 + 64 q + lane]
+    // Pass 2 and the split: the lane's row of the exchange tile, r = k1 + 32 parity; it will hold Z[r + 64 k'], k' < 32.
+    // Rows r and 64 - r, whose bins pair up in the split, sit 32 lanes apart; rows 0 and 32 pair with themselves.
+    const int rho = lane < 32 ? lane : (lane == 32 ? 32 : 96 - lane);
+    const int trow = 2 * (rho & 31) + (rho >> 5);
+    // second exchange: lane l leaves Z[r_l + 64 (16 + i)] at slot 17 l + i.  The partner of Z[r + 64 a] is
+    // Z[(64 - r) + 64 (31 - a)]: slot 15 - a of the partner lane; for row 32 of the lane itself; for row 0,
+    // Z[64 (32 - a)], slot 16 - a of the lane itself (a = 0, bin 0, pairs with itself: selected in the split).
+    const int pslot = ((lane == 0 || lane == 32) ? lane : (lane ^ 32)) * R4096_X2P + (lane == 0 ? 1 : 0);
+    const C2 ow = C2{tw[2 * rho + 1], -tw[2 * rho]};                          // -i W4096^r, for the split
+    // RUN keeps a frame's raw samples and the window in registers; the twiddles that depend on the lane alone and are
+    // used once per frame (ta) then live in LDS, behind the tiles, and are read ahead of their use
+    C2 *twl = tiles + R4096_WAVES * R4096_WAVE_C;                             // ta[q] at [64 q + lane]
     if (RUN && wv == 0) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { twl[4 * lane + c] = owm[c]; }
-#pragma unroll
-        for (int q = 1; q < 8; ++q) { twl[256 + 64 * q + lane] = ta[q]; }
+        for (int q = 1; q < 8; ++q) { twl[64 * q + lane] = ta[q]; }
     }
     __syncthreads();
 
@@ -242,16 +249,14 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         q.inside = q.ss >= 0 && q.ss + 4096 <= a.N && q.ss >= q.rdoff;
         return q;
     };
-    C2 ze[16], zo[16];      // loads: columns 2 l4 (ze) and 2 l4 + 1 (zo), rows 2 i + up; later: the two halves of a 32-point transform
-    // The first NE of a frame's 16 loads are issued a whole pass earlier than the rest, into registers of
-    // their own (the transform registers are still busy then); the window step reads them from there.
-    constexpr int NE = RUN ? 16 : R4096_EARLY;             // RUN: the 16 rows of the frame
-    float4 pre[NE > 0 ? NE : 1];
+    C2 ze[16], zo[16];      // columns 2 l4 (ze) and 2 l4 + 1 (zo), rows 2 i + up; later: the two halves of a 32-point transform
+    // A frame's 16 loads go into registers of their own (the transform registers are busy to the end of the split):
+    // frame form: issued under pass 2 of the frame before; run form: the four groups of 1024 samples of the frame
+    constexpr int NE = 16;
+    float4 pre[NE];
     const int loff = 128 * up + 4 * l4;                     // first sample of the lane inside a frame; row i adds 256
     // raw samples of a frame that lies inside its signal: 16 coalesced 1-KiB wave loads
-    auto put = [&](int i, const float4 v) {
-        if (i < NE) { pre[i] = v; } else { ze[i] = C2{v.x, v.y}; zo[i] = C2{v.z, v.w}; }
-    };
+    auto put = [&](int i, const float4 v) { pre[i] = v; };
     auto load_inside = [&](const Where &q, const int i0, const int i1) {
         const float *src = q.xb + (q.ss - q.rdoff) + loff;
 #pragma unroll
@@ -333,26 +338,26 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         for (int g = 0; g < 4; ++g) { fetch_group(find_group(b, w0, g), g); }
     };
 
-    // RUN: the halved window of the coming frame, in the rotation that frame has; read under the split of the
-    // frame before it (the transform registers' worth of values; they are free there), so that the window
-    // step does not wait for the LDS
-    constexpr int NWA = RUN ? R4096_WIN_AHEAD : 0;
-    float4 wnext[NWA > 0 ? NWA : 1];
-    auto read_window = [&](auto rot_c) __attribute__((always_inline)) {
-        constexpr int NR = decltype(rot_c)::value;
+    // WREG: the lane's 64 values of the halved window stay in registers for the whole launch (the window is full:
+    // L = 4096); a frame rotated by ROT quarters takes them in the same rotation, a renaming at compile time
+    float4 wreg[WREG ? 16 : 1];
+    if constexpr (WREG) {
 #pragma unroll
-        for (int i = 0; i < NWA; ++i) {
-            wnext[i] = *reinterpret_cast<const float4 *>(wtab + loff + 1024 * (((i >> 2) - NR) & 3) + 256 * (i & 3));
+        for (int i = 0; i < 16; ++i) {
+            const float4 w4 = *reinterpret_cast<const float4 *>(win + loff + 256 * i);
+            wreg[i] = make_float4(0.5f * w4.x, 0.5f * w4.y, 0.5f * w4.z, 0.5f * w4.w);
         }
-    };
+    }
     Where cur{};
     if constexpr (!RUN) {
         cur = locate(fid);
         if (cur.inside) { load_inside(cur, 0, 16); } else { load_edge(cur); }
     }
 #if R4096_STAMPS
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last;
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last, st_rt0;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt0) :: "memory");
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory");
+    const unsigned long long st_t0 = st_last;
 #endif
 
     // One frame: transform the samples in the registers, start the next frame's loads, write the row.
@@ -377,15 +382,12 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
             int lim = L - loff;                              // sample l = 256 i + loff + c is inside the window iff 256 i + c < lim
             asm volatile("" : "+v"(lim));                    // recomputed per frame: hoisted lane masks would not fit in SGPRs
             // RUN: register group j holds the quarter (j - tpos) % 4 of the frame
-            const float *wrow[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { wrow[j] = wtab + loff + 1024 * ((j - ROT) & 3); }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 float4 hh;
-                if (i < NWA) { hh = wnext[i]; }
-                else { hh = *reinterpret_cast<const float4 *>(wrow[i >> 2] + 256 * (i & 3)); }
-                if (i < NE) { ze[i] = C2{pre[i].x, pre[i].y}; zo[i] = C2{pre[i].z, pre[i].w}; }
+                if constexpr (WREG) { hh = wreg[4 * (((i >> 2) - ROT) & 3) + (i & 3)]; }
+                else { hh = *reinterpret_cast<const float4 *>(wtab + loff + 1024 * (((i >> 2) - ROT) & 3) + 256 * (i & 3)); }
+                ze[i] = C2{pre[i].x, pre[i].y}; zo[i] = C2{pre[i].z, pre[i].w};
                 if (!FULL) {                                 // keep data past the window out (0 * NaN)
                     ze[i].x = (256 * i < lim) ? ze[i].x : 0.f;
                     ze[i].y = (256 * i + 1 < lim) ? ze[i].y : 0.f;
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         C2 taq_r[8];
         if constexpr (RUN && R4096_TA_AHEAD) {
 #pragma unroll
-            for (int q = 1; q < 8; ++q) { taq_r[q] = twl[256 + 64 * q + lane]; }
+            for (int q = 1; q < 8; ++q) { taq_r[q] = twl[64 * q + lane]; }
             __builtin_amdgcn_sched_barrier(0);
         }
         R4096_STAMP(6);
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
 #pragma unroll
             for (int bb = 1; bb < 4; ++bb) { *zp[bb] = cx_mul_second<float>(*zp[bb], tb[bb], t[bb]); }
             if (q && !(R4096_HACK & 2)) {
-                const C2 taq = RUN ? (R4096_TA_AHEAD ? taq_r[q] : twl[256 + 64 * q + lane]) : ta[q];
+                const C2 taq = RUN ? (R4096_TA_AHEAD ? taq_r[q] : twl[64 * q + lane]) : ta[q];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int bb = 0; bb < 4; ++bb) { t[bb] = cx_mul_first<float>(*zp[bb], taq); }
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
             C2 &z = (k1 < 16) ? ze[slot16(k1)] : zo[slot16(k1 - 16)];
             const int q = k1 >> 2, bb = k1 & 3;
             if (bb) { z = cx_mul<float>(z, tb[bb]); }
-            if (q) { z = cx_mul<float>(z, RUN ? twl[256 + 64 * q + lane] : ta[q]); }
+            if (q) { z = cx_mul<float>(z, RUN ? twl[64 * q + lane] : ta[q]); }
         }
 #endif
         // first radix-2 stage of the 64-point transforms over n2: columns n2 and n2 + 32 sit 16 lanes
@@ -517,13 +519,13 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
 #if R4096_LOCKSTEP
             if ((iter++ & (R4096_LOCK_EVERY - 1)) == 0) { __builtin_amdgcn_s_barrier(); }   // the workgroup's 8 waves request neighbouring frames together
 #endif
-            if (NE > 0 && nxt.inside) { load_inside(nxt, 0, NE); }
+            if (nxt.inside) { load_inside(nxt, 0, 16); }
         }
         R4096_STAMP(1);
 
-        // ---------------- pass 2: lane = row (k1, parity): 32-point FFT ----------------
+        // ---------------- pass 2: the lane's row (k1, parity): 32-point FFT ----------------
         {
-            const C2 *row = ex + lane * R4096_PITCH;
+            const C2 *row = ex + trow * R4096_PITCH;
 #pragma unroll
             for (int m = 0; m < 16; ++m) { ze[m] = row[m]; zo[m] = row[16 + m]; }   // even / odd columns
         }
@@ -531,102 +533,90 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         dft32c(ze, zo);
         R4096_STAMP(2);
         R4096_PRIO(2, 1);
-        wave_sync();                                       // every lane has its row: the tile becomes Z
+        wave_sync();                                       // every lane has its row: the tile is free
+        // second exchange: the upper half of the lane's values, Z[r + 64 (16 + i)], for its partner
         {
-            C2 *zdst = ex + zpos((lane >> 1) + 32 * (lane & 1));   // Z[k1 + 32 parity + 64 k']
+            C2 *x2w = ex + lane * R4096_X2P;
 #pragma unroll
-            for (int kp = 0; kp < 32; ++kp) {
-                zdst[64 * kp] = (kp < 16) ? ze[slot16(kp)] : zo[slot16(kp - 16)];
-            }
+            for (int i = 0; i < 16; ++i) { x2w[i] = zo[slot16(i)]; }
         }
         wave_sync();
         R4096_STAMP(3);
-
-        // the registers are free from here on: start the next frame's loads under the split
-        if (!RUN && nxt.inside) { load_inside(nxt, NE, 16); }
-        if constexpr (NWA > 0) {
-            read_window(rot<(ROT + 1) & 3>{});
-            __builtin_amdgcn_sched_barrier(0);
-        }
         R4096_STAMP(4);
 
-        // ---------------- split + power + store: lane handles bins k = 4 lane + c + 256 m and 2048 - k ----------------
-        float *y = Y + (RUN ? (long long)run_b * a.Wy + run_w0 + tpos : cur.row) * ((R4096_HACK & 4) ? 2048 : (CPLX ? 2 * F : F));
-        const C2 *zk = ex + zpos(4 * lane);                                // Z[k] at zk[256 m + c]
-        const C2 *zq0 = ex + zpos(M - 4 * lane) - 768;                     // Z[2048 - 4 lane - 256 m] at zq0[256 (3 - m)]
-        const C2 *zq4 = ex + zpos(M - 4 - 4 * lane) - 768;                 // Z[2048 - 4 lane - 256 m - 4 + i] at zq4[256 (3 - m) + i]
-        C2 ow4[4];
+        // ---------------- split + power + store: the lane's bins k = r + 64 a, a < 16, and 2048 - k ----------------
+        float *y = Y + (RUN ? (long long)run_b * a.Wy + run_w0 + tpos : cur.row) * (CPLX ? 2 * F : F);
+        const C2 *zpart = ex + pslot;                                      // Z[2048 - k] at zpart[15 - a]
+        float *yf = y + (CPLX ? 2 : 1) * rho, *yr = y + (CPLX ? 2 : 1) * (M - rho);
+        [[maybe_unused]] C2 cu = C2{0.f, 0.f};
+        if constexpr (CPLX) {
+            // the rotation of the run form undone: bin k times i^(ROT k) = i^(ROT r), bin 2048 - k times its conjugate
+            constexpr int RC = RUN ? ROT : 0;
+            const int e = (RC * rho) & 3;
+            const float sc = a.cscale;
+            cu = C2{e == 0 ? sc : (e == 2 ? -sc : 0.f), e == 1 ? sc : (e == 3 ? -sc : 0.f)};
+        }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { ow4[c] = RUN ? twl[4 * lane + c] : owm[c]; }
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int g = 0; g < 4; ++g) {
             float p[4], q[4];
-            C2 xu[4], xv[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const C2 z = zk[256 * m + c];
-                C2 zm = (c == 0) ? zq0[256 * (3 - m)] : zq4[256 * (3 - m) + 4 - c];
-                if (m == 0 && c == 0) { zm = (lane == 0) ? z : zm; }         // bin 0 pairs with itself
+                const int aa = 4 * g + c;
+                const C2 z = ze[slot16(aa)];
+                C2 zm = zpart[15 - aa];
+                if (aa == 0) { zm = (lane == 0) ? z : zm; }                // bin 0 pairs with itself
                 const C2 A = cx_add_conj<float>(z, zm);
                 C2 B = cx_sub_conj<float>(z, zm);
-                // -i W4096^k B with W4096^k = W4096^(4 lane + c) W16^m
+                // -i W4096^k B with W4096^k = W4096^r W64^a
 #if !(R4096_HACK & 1)
-                if (m > 0) { B = cx_mul<float>(B, W64C[8 * m], W64C[8 * m + 1]); }
+                if (aa > 0) { B = cx_mul<float>(B, W64C[2 * aa], W64C[2 * aa + 1]); }
 #endif
-                const C2 Tw = cx_mul<float>(B, ow4[c]);
+                const C2 Tw = cx_mul<float>(B, ow);
                 if constexpr (CPLX) {
-                    // X_k = A + T, X_(2048-k) = conj(A - T); times i^(ROT c) and i^(-ROT c): the rotation of the run form undone
+                    // X_k = A + T, X_(2048-k) = conj(A - T)
                     constexpr int RC = RUN ? ROT : 0;
-                    const float sc = a.cscale;
-                    C2 u = (A + Tw) * C2{sc, sc}, v = (A - Tw) * C2{sc, -sc};
-                    const int pu = (RC * c) & 3, pv = (4 - ((RC * c) & 3)) & 3;
-                    auto times_i_pow = [](const C2 w, const int e) {           // w * i^e
-                        return e == 0 ? w : e == 1 ? C2{-w.y, w.x} : e == 2 ? C2{-w.x, -w.y} : C2{w.y, -w.x};
-                    };
-                    u = times_i_pow(u, pu); v = times_i_pow(v, pv);
-                    if (m == 0 && c == 0) { u.y = (lane == 0) ? 0.f : u.y; v.y = (lane == 0) ? 0.f : v.y; }   // bins 0 and 2048
-                    xu[c] = u; xv[c] = v;
+                    C2 u, v;
+                    if constexpr (RC == 0) { u = (A + Tw) * C2{cu.x, cu.x}; v = (A - Tw) * C2{cu.x, -cu.x}; }
+                    else { u = cx_mul<float>(A + Tw, cu); v = cx_mul<float>(A - Tw, cu) * C2{1.f, -1.f}; }
+                    if (aa == 0) { u.y = (lane == 0) ? 0.f : u.y; v.y = (lane == 0) ? 0.f : v.y; }   // bins 0 and 2048
+                    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+                    *reinterpret_cast<f2u *>(yf + 128 * aa) = f2u{u.x, u.y};
+                    *reinterpret_cast<f2u *>(yr - 128 * aa) = f2u{v.x, v.y};
                 } else {
                     p[c] = cx_norm<float>(A + Tw); q[c] = cx_norm<float>(A - Tw);
                 }
             }
+            if constexpr (CPLX) { continue; }
             if (EPI) { power_epilogue_n(p, a.epi); power_epilogue_n(q, a.epi); }
-            const int k0 = 4 * lane + 256 * m;
-            if constexpr (CPLX) {
-                // bins k0 .. k0 + 3 and 2045 - k0 .. 2048 - k0: 32 bytes each way
-                float *yf = y + 2 * k0, *yr = y + 2 * (M - 3 - k0);
-                *reinterpret_cast<float4_u *>(yf) = float4_u{xu[0].x, xu[0].y, xu[1].x, xu[1].y};
-                *reinterpret_cast<float4_u *>(yf + 4) = float4_u{xu[2].x, xu[2].y, xu[3].x, xu[3].y};
-                *reinterpret_cast<float4_u *>(yr) = float4_u{xv[3].x, xv[3].y, xv[2].x, xv[2].y};
-                *reinterpret_cast<float4_u *>(yr + 4) = float4_u{xv[1].x, xv[1].y, xv[0].x, xv[0].y};
-                continue;
-            }
 #if R4096_ABLATE & 1
             asm volatile("" :: "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]));
             if (a.N == -12345)
 #endif
             {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
 #if R4096_NT_STORE
-                __builtin_nontemporal_store(float4_u{p[0], p[1], p[2], p[3]}, reinterpret_cast<float4_u *>(y + k0));
-                __builtin_nontemporal_store(float4_u{q[3], q[2], q[1], q[0]}, reinterpret_cast<float4_u *>(y + M - ((R4096_HACK & 4) ? 4 : 3) - k0));
+                    __builtin_nontemporal_store(p[c], yf + 64 * (4 * g + c));
+                    __builtin_nontemporal_store(q[c], yr - 64 * (4 * g + c));
 #else
-                *reinterpret_cast<float4_u *>(y + k0) = float4_u{p[0], p[1], p[2], p[3]};
-                *reinterpret_cast<float4_u *>(y + M - ((R4096_HACK & 4) ? 4 : 3) - k0) = float4_u{q[3], q[2], q[1], q[0]};
+                    yf[64 * (4 * g + c)] = p[c];
+                    yr[-64 * (4 * g + c)] = q[c];
 #endif
+                }
             }
         }
         {
-            // bin 1024 pairs with itself (Z holds half values).  Every lane stores the same value to the
-            // same address: a store under `if (lane == 0)` sits behind a branch, the count of stores after
-            // the prefetch loads is then unknown at compile time, and the wait for the loads also waits
-            // for the first store of this row to complete.
+            // bin 1024 = row 0, k' = 16: the first value lane 0 left in the second exchange.  It pairs with itself (Z
+            // holds half values).  Every lane stores the same value to the same address: a store under
+            // `if (lane == 0)` sits behind a branch, the count of stores after the prefetch loads is then
+            // unknown at compile time, and the wait for the loads also waits for the first store of this row.
+            const C2 zmid = ex[0];
             if constexpr (CPLX) {
-                // bin 1024 is 2 conj Z_1024 (times i^(ROT 1024) = 1); stored by every lane, as the power form's is
-                const C2 zmid = ex[1024];
+                // bin 1024 is 2 conj Z_1024 (times i^(ROT 1024) = 1)
                 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
                 *reinterpret_cast<f2u *>(y + 2048) = f2u{2.0f * a.cscale * zmid.x, -2.0f * a.cscale * zmid.y};
             }
-            float p = 4.0f * cx_norm<float>(ex[1024]);
+            float p = 4.0f * cx_norm<float>(zmid);
             if (EPI) { p = power_epilogue(p, a.epi); }
 #if R4096_ABLATE & 1
             asm volatile("" :: "v"(p));
@@ -661,16 +651,22 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
             asm volatile("" : "+v"(took) : "v"(pre[3].w), "v"(pre[7].w), "v"(pre[11].w), "v"(pre[15].w));
             const int nrun = f_lo + fstride + (int)__builtin_amdgcn_readfirstlane(took);
             tpos = 0;
-            if constexpr (NWA > 0) { read_window(rot<0>{}); }
             while (frame(rot<0>{}) && frame(rot<1>{}) && frame(rot<2>{}) && frame(rot<3>{})) { }
             fid = nrun;
         }
     } else {
         if (frame(rot<0>{})) { while (frame(rot<0>{})) { } }
     }
+    unsigned long long st_t1, st_rt1;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t1) :: "memory");
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt1) :: "memory");
     if (lane == 0) {
         const int gw = blockIdx.x * R4096_WAVES + wv;
-        if (gw < 2048) { for (int i = 0; i < 8; ++i) { g_r4096_stamps[gw * 8 + i] = st_acc[i]; } }
+        if (gw < 2048) {
+            for (int i = 0; i < 8; ++i) { g_r4096_stamps[gw * 10 + i] = st_acc[i]; }
+            g_r4096_stamps[gw * 10 + 8] = st_t1 - st_t0;
+            g_r4096_stamps[gw * 10 + 9] = st_rt1 - st_rt0;
+        }
     }
 #else
     if constexpr (RUN) {
@@ -688,7 +684,6 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
             asm volatile("" : "+v"(took) : "v"(pre[3].w), "v"(pre[7].w), "v"(pre[11].w), "v"(pre[15].w));
             const int nrun = f_lo + fstride + (int)__builtin_amdgcn_readfirstlane(took);
             tpos = 0;
-            if constexpr (NWA > 0) { read_window(rot<0>{}); }
             while (frame(rot<0>{}) && frame(rot<1>{}) && frame(rot<2>{}) && frame(rot<3>{})) { }
             fid = nrun;
         }
@@ -726,7 +721,7 @@ bool g_take_busy[64][R4096_SLOTS];
 template <bool FULL, bool MN0, bool EPI, bool RUN, bool CPLX = false>
 static hipError_t launch_r4096_inst(float *Y, const float *X, const float *win, const float *tw, const R4096Args &a, hipStream_t s, unsigned *take)
 {
-    const size_t lds = 4096 * sizeof(float) + (size_t)R4096_WAVES * R4096_WAVE_C * sizeof(float2) + (RUN ? (256 + 64 * 8) * sizeof(float2) : 0);
+    const size_t lds = (size_t)R4096_WAVES * R4096_WAVE_C * sizeof(float2) + (RUN ? (64 * 8) * sizeof(float2) : 0) + (r4096_wreg(MN0, EPI, RUN, CPLX) ? 0 : 4096 * sizeof(float));
     static LdsGrant grant;
     if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r4096_kernel<FULL, MN0, EPI, RUN, CPLX>), lds, grant); e != hipSuccess) { return e; }
     long long grid = ((long long)a.frames + R4096_WAVES - 1) / R4096_WAVES;

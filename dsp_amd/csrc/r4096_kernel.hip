@@ -5,21 +5,19 @@
 // The 4096 real samples of a frame are packed as 2048 complex points z_n = x_2n + i x_2n+1 and
 // transformed as 32 x 64, every complex value one (re, im) register pair so that the butterflies
 // run on the packed two-component float instructions:
-//   loads   half-wave u takes the rows n1 = 2 i + u, lane l of it the complex columns 2 l and 2 l + 1:
-//           sixteen 16-byte loads per lane, each wave load 1 KiB contiguous;
-//   pass 1  window (LDS, 16-byte reads), two 16-point FFTs over the half-wave's rows, then one
-//           v_permlane32_swap per register trades a column between the half-waves: every lane holds the
-//           even-row and odd-row transforms of ONE column n2 = 2 l + u and finishes the 32-point FFT in
-//           registers; twiddle W2048^(n2 k1) as two per-lane factors (k1 = 4 q + b);
+//   loads   lane l is the complex column n2 = l and takes its 32 rows n1: thirty-two 8-byte loads per lane, each
+//           wave load 512 contiguous bytes (the run form below loads only a quarter of them per frame);
+//   pass 1  window (registers or LDS), one 32-point FFT over the rows in registers (two 16-point transforms
+//           and 16 butterflies, the constant twiddles folded into the additions: fft16.h); twiddle
+//           W2048^(n2 k1) as two per-lane factors (k1 = 4 q + b);
 //   radix-2 the first (decimation-in-frequency) stage of the 64-point transforms over n2 pairs column
-//           n2 with n2 + 32, 16 lanes apart: one v_permlane16_swap of rows k1 and k1 + 16 gives every
+//           n2 with n2 + 32, 32 lanes apart: one v_permlane32_swap of rows k1 and k1 + 16 gives every
 //           lane both inputs of its butterfly; u = x + y feeds the even outputs, v = (x - y) W64^n2
 //           the odd ones;
-//   exchange through LDS: 64 rows (k1, parity) of 32 values, pitch 33 (conflict-free both ways);
-//   pass 2  lane (k1, parity) runs one 32-point FFT and holds Z[k1 + 32 parity + 64 k'];
-//   split   the lanes are given their rows so that row r (lanes 0..31) and row 64 - r (lanes 32..63) sit 32
-//           lanes apart: of the pair Z[k], Z[2048 - k] that the real-FFT split needs, a lane holds Z[k] for
-//           k = r + 64 a, a < 16, itself and fetches the other from its partner's upper 16 values, which go
+//   exchange through LDS: 64 rows r = k1 + 32 parity of 32 values, pitch 33 (conflict-free both ways);
+//   pass 2  lane r runs one 32-point FFT and holds Z[r + 64 k'];
+//   split   of the pair Z[k], Z[2048 - k] that the real-FFT split needs, lane r holds Z[k] for k = r + 64 a,
+//           a < 16, itself and fetches the other from the upper 16 values of lane 64 - r, which go
 //           through LDS once (8.5 KB per frame instead of the whole spectrum both ways); split and power
 //           in registers; a store instruction writes 64 consecutive bins, one per lane.
 // Two forms of the frame loop (template parameter RUN): with a full window and a hop of 1024 a wave
@@ -61,7 +59,7 @@ constexpr int R4096_WAVE_C = 64 * R4096_PITCH;          // complex slots per wav
 #define R4096_NWAVES 8
 #endif
 constexpr int R4096_WAVES = R4096_NWAVES;               // waves per workgroup (share the window table)
-typedef float2 __attribute__((aligned(4))) float2_u;    // frame starts are only 4-byte aligned
+typedef float float2_u __attribute__((ext_vector_type(2), aligned(4)));   // 8-byte access at 4-byte alignment (frame starts are only 4-byte aligned)
 typedef unsigned u2v __attribute__((ext_vector_type(2)));
 typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access at 4-byte alignment
 
@@ -116,34 +114,19 @@ __device__ unsigned long long g_r4096_stamps[2048 * 10];   // per wave: 8 phase 
 #define R4096_STAMP(i) do {} while (0)
 #endif
 
-// W32^k, k < 16, and W64^k, k < 32, as (cos, -sin)(2 pi k / n) pairs; indexed with compile-time
+// W64^k, k < 32, as (cos, -sin)(2 pi k / 64) pairs; indexed with compile-time
 // constants only, so they fold into the instructions as literals
-__device__ constexpr float W32C[32] = {1.000000000e+00f, -0.000000000e+00f, 9.807852507e-01f, -1.950903237e-01f, 9.238795042e-01f, -3.826834261e-01f, 8.314695954e-01f, -5.555702448e-01f, 7.071067691e-01f, -7.071067691e-01f, 5.555702448e-01f, -8.314695954e-01f, 3.826834261e-01f, -9.238795042e-01f, 1.950903237e-01f, -9.807852507e-01f, 6.123234263e-17f, -1.000000000e+00f, -1.950903237e-01f, -9.807852507e-01f, -3.826834261e-01f, -9.238795042e-01f, -5.555702448e-01f, -8.314695954e-01f, -7.071067691e-01f, -7.071067691e-01f, -8.314695954e-01f, -5.555702448e-01f, -9.238795042e-01f, -3.826834261e-01f, -9.807852507e-01f, -1.950903237e-01f};
 __device__ constexpr float W64C[64] = {1.000000000e+00f, -0.000000000e+00f, 9.951847196e-01f, -9.801714122e-02f, 9.807852507e-01f, -1.950903237e-01f, 9.569403529e-01f, -2.902846634e-01f, 9.238795042e-01f, -3.826834261e-01f, 8.819212914e-01f, -4.713967443e-01f, 8.314695954e-01f, -5.555702448e-01f, 7.730104327e-01f, -6.343932748e-01f, 7.071067691e-01f, -7.071067691e-01f, 6.343932748e-01f, -7.730104327e-01f, 5.555702448e-01f, -8.314695954e-01f, 4.713967443e-01f, -8.819212914e-01f, 3.826834261e-01f, -9.238795042e-01f, 2.902846634e-01f, -9.569403529e-01f, 1.950903237e-01f, -9.807852507e-01f, 9.801714122e-02f, -9.951847196e-01f, 6.123234263e-17f, -1.000000000e+00f, -9.801714122e-02f, -9.951847196e-01f, -1.950903237e-01f, -9.807852507e-01f, -2.902846634e-01f, -9.569403529e-01f, -3.826834261e-01f, -9.238795042e-01f, -4.713967443e-01f, -8.819212914e-01f, -5.555702448e-01f, -8.314695954e-01f, -6.343932748e-01f, -7.730104327e-01f, -7.071067691e-01f, -7.071067691e-01f, -7.730104327e-01f, -6.343932748e-01f, -8.314695954e-01f, -5.555702448e-01f, -8.819212914e-01f, -4.713967443e-01f, -9.238795042e-01f, -3.826834261e-01f, -9.569403529e-01f, -2.902846634e-01f, -9.807852507e-01f, -1.950903237e-01f, -9.951847196e-01f, -9.801714122e-02f};
 
 using C2 = cx<float>;
-
-// forward 32-point DFT of x[n], n = 0..31, given as even part e[m] = x[2m] and odd part o[m] = x[2m+1].
-// On return X[k] is in e[slot16(k)] for k < 16 and in o[slot16(k - 16)] for k >= 16.
-__device__ __forceinline__ void dft32c(C2 (&e)[16], C2 (&o)[16])
-{
-    dft16c<float, 16>(e);
-    dft16c<float, 16>(o);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int s = slot16(k);
-        C2 t = o[s];
-        if (k == 8) { t = cx_swap(t) * C2{1.f, -1.f}; }
-        else if (k > 0) { t = cx_mul<float>(t, W32C[2 * k], W32C[2 * k + 1]); }
-        o[s] = e[s] - t;
-        e[s] = e[s] + t;
-    }
-}
 
 constexpr int R4096_X2P = 17;                           // second exchange: complex slots per lane (16 values + 1)
 // which instantiations keep the window in registers instead of LDS: the run form without mean removal, epilogue or
 // complex rows (those need the registers themselves)
 constexpr bool r4096_wreg(bool mn0, bool epi, bool run, bool cplx) { return run && !mn0 && !epi && !cplx; }
+
+// |a|^2 as a plain multiply and a plain fma: 2 + 2 issue cycles, where the packed square and the add of its halves take 4 + 2
+__device__ __forceinline__ float norm2(const C2 a) { return fmaf(a.y, a.y, a.x * a.x); }
 
 template <int R> using rot = std::integral_constant<int, R>;
 
@@ -173,12 +156,10 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         for (int l = tid; l < 4096; l += 64 * R4096_WAVES) { wtab[l] = (l < L) ? 0.5f * win[l] : 0.0f; }
     }
 
-    // Lane roles.  Loads: half-wave u takes the rows n1 = 2 i + u, lane l4 of it the complex columns
-    // 2 l4 and 2 l4 + 1 (one 16-byte load per row).  After the 16-point transforms one swap between the
-    // half-waves leaves every lane with both halves of ONE column, n2 = 2 l4 + u.
-    const int l4 = lane & 31, up = lane >> 5;
-    const int n2 = 2 * l4 + up;
-    const int hi16 = (lane >> 4) & 1, j16 = lane & 15;         // n2 = 32 hi16 + 2 j16 + up
+    // Lane roles.  Pass 1: the lane is the complex column n2 = lane and holds its 32 rows n1 (z[n2 + 64 n1] = samples
+    // 128 n1 + 2 lane, + 1): an 8-byte load per row, 512 contiguous bytes per wave load.  Pass 2 and the split: the lane is
+    // the row r = lane of the exchange tile (r = k1 + 32 parity) and holds Z[r + 64 k'], k' < 32.
+    const int n2 = lane, jj = lane & 31, hh2 = lane >> 5;
     // per-lane twiddles: W2048^(n2 b), b = 1..3, and W2048^(4 n2 a), a = 1..7
     auto tw2048 = [&](int m) {                            // W2048^m = W4096^(2m), table holds k < 2048
         int idx = (2 * m) & 4095;
@@ -191,18 +172,14 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
     for (int b = 1; b < 4; ++b) { tb[b] = tw2048(n2 * b); }
 #pragma unroll
     for (int q = 1; q < 8; ++q) { ta[q] = tw2048(4 * n2 * q); }
-    const C2 wl = C2{tw[2 * 64 * (n2 & 31)], tw[2 * 64 * (n2 & 31) + 1]};   // W64^(n2 % 32)
-    // Pass 2 and the split: the lane's row of the exchange tile, r = k1 + 32 parity; it will hold Z[r + 64 k'], k' < 32.
-    // Rows r and 64 - r, whose bins pair up in the split, sit 32 lanes apart; rows 0 and 32 pair with themselves.
-    const int rho = lane < 32 ? lane : (lane == 32 ? 32 : 96 - lane);
-    const int trow = 2 * (rho & 31) + (rho >> 5);
-    // second exchange: lane l leaves Z[r_l + 64 (16 + i)] at slot 17 l + i.  The partner of Z[r + 64 a] is
-    // Z[(64 - r) + 64 (31 - a)]: slot 15 - a of the partner lane; for row 32 of the lane itself; for row 0,
-    // Z[64 (32 - a)], slot 16 - a of the lane itself (a = 0, bin 0, pairs with itself: selected in the split).
-    const int pslot = ((lane == 0 || lane == 32) ? lane : (lane ^ 32)) * R4096_X2P + (lane == 0 ? 1 : 0);
-    const C2 ow = C2{tw[2 * rho + 1], -tw[2 * rho]};                          // -i W4096^r, for the split
-    // RUN keeps a frame's raw samples and the window in registers; the twiddles that depend on the lane alone and are
-    // used once per frame (ta) then live in LDS, behind the tiles, and are read ahead of their use
+    const C2 wl = C2{tw[2 * 64 * jj], tw[2 * 64 * jj + 1]};                   // W64^(n2 % 32)
+    // Second exchange: lane l leaves Z[l + 64 (16 + i)] at slot 17 l + i.  The split pairs Z[r + 64 a] with
+    // Z[2048 - r - 64 a] = Z[(64 - r) + 64 (31 - a)]: slot 15 - a of lane 64 - r; for r = 32 that is the lane itself; for
+    // r = 0 the partner is Z[64 (32 - a)], slot 16 - a of the lane itself (a = 0, bin 0, pairs with itself: selected in the split).
+    const int pslot = ((64 - lane) & 63) * R4096_X2P + (lane == 0 ? 1 : 0);
+    const C2 ow = C2{tw[2 * lane + 1], -tw[2 * lane]};                        // -i W4096^r, for the split
+    // RUN keeps a frame's raw samples (and, WREG, the window) in registers; the twiddles that depend on the lane alone and
+    // are used once per frame (ta) then live in LDS, behind the tiles, and are read ahead of their use
     C2 *twl = tiles + R4096_WAVES * R4096_WAVE_C;                             // ta[q] at [64 q + lane]
     if (RUN && wv == 0) {
 #pragma unroll
@@ -213,8 +190,8 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
     // Work distribution, two forms.
     // Runs (RUN: full window, uniform hop of 1024 = a quarter of the frame): a wave takes runs of
     // R4096_RUN consecutive frames of one signal and reads it as a stream of groups of 1024 samples:
-    // frame t of the run is groups t .. t + 3, and group g lives in the registers pre[4 (g % 4) ..].
-    // Once the window step of frame t has read them, the 4 wave loads of group t + 4 go out into the
+    // frame t of the run is groups t .. t + 3, and group g lives in the registers pre[8 (g % 4) ..].
+    // Once the window step of frame t has read them, the 8 wave loads of group t + 4 go out into the
     // registers of group t, a whole frame before they are waited for.  The registers thus hold frame t
     // rotated by t % 4 quarters; the window is applied with the same rotation and the transform is taken
     // of the rotated frame, whose power spectrum is that of the frame itself (a circular shift by a
@@ -249,25 +226,22 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         q.inside = q.ss >= 0 && q.ss + 4096 <= a.N && q.ss >= q.rdoff;
         return q;
     };
-    C2 ze[16], zo[16];      // columns 2 l4 (ze) and 2 l4 + 1 (zo), rows 2 i + up; later: the two halves of a 32-point transform
-    // A frame's 16 loads go into registers of their own (the transform registers are busy to the end of the split):
+    C2 ze[16], zo[16];      // even rows (ze) and odd rows (zo) of the column; later: the two halves of a 32-point transform
+    // A frame's 32 loads go into registers of their own (the transform registers are busy to the end of the split):
     // frame form: issued under pass 2 of the frame before; run form: the four groups of 1024 samples of the frame
-    constexpr int NE = 16;
-    float4 pre[NE];
-    const int loff = 128 * up + 4 * l4;                     // first sample of the lane inside a frame; row i adds 256
-    // raw samples of a frame that lies inside its signal: 16 coalesced 1-KiB wave loads
-    auto put = [&](int i, const float4 v) { pre[i] = v; };
-    auto load_inside = [&](const Where &q, const int i0, const int i1) {
+    C2 pre[32];
+    const int loff = 2 * lane;                              // first sample of the lane inside a frame; row i adds 128
+    // raw samples of a frame that lies inside its signal: 32 coalesced 512-byte wave loads
+    auto load_inside = [&](const Where &q) {
         const float *src = q.xb + (q.ss - q.rdoff) + loff;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if (i < i0 || i >= i1) { continue; }
-            float4_u v = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 32; ++i) {
+            float2_u v = {0.f, 0.f};
 #if R4096_ABLATE & 2
             if (a.N == -12345)
 #endif
-            if (FULL || 256 * i < L) { v = *reinterpret_cast<const float4_u *>(src + 256 * i); }
-            put(i, make_float4(v.x, v.y, v.z, v.w));
+            if (FULL || 128 * i < L) { v = *reinterpret_cast<const float2_u *>(src + 128 * i); }
+            pre[i] = C2{v.x, v.y};
         }
     };
     // a frame that crosses an edge of its signal: gather sample by sample into the (idle) tile first
@@ -279,9 +253,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         for (int l = lane; l < 4096; l += 64) { stage[l] = (l < L) ? fetch_sample(q.xb, d, q.ss, q.rdoff, l) : 0.f; }
         wave_sync();
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            put(i, *reinterpret_cast<const float4 *>(stage + loff + 256 * i));
-        }
+        for (int i = 0; i < 32; ++i) { pre[i] = *reinterpret_cast<const C2 *>(stage + loff + 128 * i); }
         asm volatile("" ::: "memory");                 // keeps these LDS reads from being merged with load_inside's into flat loads
     };
 
@@ -312,22 +284,22 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         }
         return q;
     };
-    // ... and into the registers of group slot j: 4 coalesced 1-KiB wave loads (or the staged copy)
+    // ... and into the registers of group slot j: 8 coalesced 512-byte wave loads (or the staged copy)
     auto fetch_group = [&](const Group &q, const int j) {
         if (q.inside) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < 8; ++r) {
 #if R4096_NT_LOAD
-                const float4_u v = __builtin_nontemporal_load(reinterpret_cast<const float4_u *>(q.src + 256 * r));
+                const float2_u v = __builtin_nontemporal_load(reinterpret_cast<const float2_u *>(q.src + 128 * r));
 #else
-                const float4_u v = *reinterpret_cast<const float4_u *>(q.src + 256 * r);
+                const float2_u v = *reinterpret_cast<const float2_u *>(q.src + 128 * r);
 #endif
-                pre[4 * j + r] = make_float4(v.x, v.y, v.z, v.w);
+                pre[8 * j + r] = C2{v.x, v.y};
             }
         } else {
             const float *stage = reinterpret_cast<const float *>(ex);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { pre[4 * j + r] = *reinterpret_cast<const float4 *>(stage + loff + 256 * r); }
+            for (int r = 0; r < 8; ++r) { pre[8 * j + r] = *reinterpret_cast<const C2 *>(stage + loff + 128 * r); }
             asm volatile("" ::: "memory");
         }
     };
@@ -340,18 +312,18 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
 
     // WREG: the lane's 64 values of the halved window stay in registers for the whole launch (the window is full:
     // L = 4096); a frame rotated by ROT quarters takes them in the same rotation, a renaming at compile time
-    float4 wreg[WREG ? 16 : 1];
+    C2 wreg[WREG ? 32 : 1];
     if constexpr (WREG) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float4 w4 = *reinterpret_cast<const float4 *>(win + loff + 256 * i);
-            wreg[i] = make_float4(0.5f * w4.x, 0.5f * w4.y, 0.5f * w4.z, 0.5f * w4.w);
+        for (int i = 0; i < 32; ++i) {
+            const float2 w2 = *reinterpret_cast<const float2 *>(win + loff + 128 * i);
+            wreg[i] = C2{0.5f * w2.x, 0.5f * w2.y};
         }
     }
     Where cur{};
     if constexpr (!RUN) {
         cur = locate(fid);
-        if (cur.inside) { load_inside(cur, 0, 16); } else { load_edge(cur); }
+        if (cur.inside) { load_inside(cur); } else { load_edge(cur); }
     }
 #if R4096_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last, st_rt0;
@@ -359,6 +331,17 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory");
     const unsigned long long st_t0 = st_last;
 #endif
+
+    // forward 32-point DFT of x[n], n < 32, given as even part e[m] = x[2m] and odd part o[m] = x[2m+1]; on return X[k]
+    // is in e[slot16(k)] for k < 16 and in o[slot16(k - 16)] for k >= 16.  Twiddles folded into the additions (fft16.h).
+    auto dft32f = [](C2 (&e)[16], C2 (&o)[16]) __attribute__((always_inline)) {
+        dft16f<float, 16>(e);
+        dft16f<float, 16>(o);
+#define R4096_B(K) bfly_tw<float, 32, K>(e[slot16(K)], o[slot16(K)]);
+        R4096_B(0) R4096_B(1) R4096_B(2) R4096_B(3) R4096_B(4) R4096_B(5) R4096_B(6) R4096_B(7)
+        R4096_B(8) R4096_B(9) R4096_B(10) R4096_B(11) R4096_B(12) R4096_B(13) R4096_B(14) R4096_B(15)
+#undef R4096_B
+    };
 
     // One frame: transform the samples in the registers, start the next frame's loads, write the row.
     // Returns false after the last frame (RUN: of the run).  The first frame runs in a copy of its own, so that inside
@@ -379,24 +362,23 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         R4096_PRIO(4, 1);
         {
             C2 acc = C2{0.f, 0.f};
-            int lim = L - loff;                              // sample l = 256 i + loff + c is inside the window iff 256 i + c < lim
+            int lim = L - loff;                              // sample l = 128 i + loff + c is inside the window iff 128 i + c < lim
             asm volatile("" : "+v"(lim));                    // recomputed per frame: hoisted lane masks would not fit in SGPRs
-            // RUN: register group j holds the quarter (j - tpos) % 4 of the frame
+            // RUN: register group j (rows 8 j .. 8 j + 7) holds the quarter (j - tpos) % 4 of the frame
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float4 hh;
-                if constexpr (WREG) { hh = wreg[4 * (((i >> 2) - ROT) & 3) + (i & 3)]; }
-                else { hh = *reinterpret_cast<const float4 *>(wtab + loff + 1024 * (((i >> 2) - ROT) & 3) + 256 * (i & 3)); }
-                ze[i] = C2{pre[i].x, pre[i].y}; zo[i] = C2{pre[i].z, pre[i].w};
+            for (int i = 0; i < 32; ++i) {
+                const int wi = 8 * (((i >> 3) - ROT) & 3) + (i & 7);      // the row's place in the frame
+                C2 hw;
+                if constexpr (WREG) { hw = wreg[wi]; }
+                else { hw = *reinterpret_cast<const C2 *>(wtab + loff + 128 * wi); }
+                C2 v = pre[i];
                 if (!FULL) {                                 // keep data past the window out (0 * NaN)
-                    ze[i].x = (256 * i < lim) ? ze[i].x : 0.f;
-                    ze[i].y = (256 * i + 1 < lim) ? ze[i].y : 0.f;
-                    zo[i].x = (256 * i + 2 < lim) ? zo[i].x : 0.f;
-                    zo[i].y = (256 * i + 3 < lim) ? zo[i].y : 0.f;
+                    v.x = (128 * i < lim) ? v.x : 0.f;
+                    v.y = (128 * i + 1 < lim) ? v.y : 0.f;
                 }
-                ze[i] = ze[i] * C2{hh.x, hh.y};
-                zo[i] = zo[i] * C2{hh.z, hh.w};
-                if (MN0) { acc += ze[i] + zo[i]; }
+                v = v * hw;
+                if (MN0) { acc += v; }
+                if (i & 1) { zo[i >> 1] = v; } else { ze[i >> 1] = v; }
             }
             if (MN0) {
                 float sum = acc.x + acc.y;
@@ -404,9 +386,9 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
                 for (int o = 1; o < 64; o <<= 1) { sum += __shfl_xor(sum, o); }
                 const float mean = sum / (float)L;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    ze[i] -= C2{(FULL || 256 * i < lim) ? mean : 0.f, (FULL || 256 * i + 1 < lim) ? mean : 0.f};
-                    zo[i] -= C2{(FULL || 256 * i + 2 < lim) ? mean : 0.f, (FULL || 256 * i + 3 < lim) ? mean : 0.f};
+                for (int i = 0; i < 32; ++i) {
+                    const C2 mm = C2{(FULL || 128 * i < lim) ? mean : 0.f, (FULL || 128 * i + 1 < lim) ? mean : 0.f};
+                    if (i & 1) { zo[i >> 1] -= mm; } else { ze[i >> 1] -= mm; }
                 }
             }
         }
@@ -435,23 +417,8 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
             }
         }
         R4096_STAMP(7);
-        // 16-point transforms over this half-wave's rows, for both columns; then the half-waves trade
-        // one column each, so that a lane holds E (even rows) and O (odd rows) of column n2, and
-        // X[k1] = E + W32^k1 O, X[k1 + 16] = E - W32^k1 O
-        dft16c<float, 16>(ze);
-        dft16c<float, 16>(zo);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int s = slot16(k);
-            const u2v sr = __builtin_amdgcn_permlane32_swap(__float_as_uint(ze[s].x), __float_as_uint(zo[s].x), false, false);
-            const u2v si = __builtin_amdgcn_permlane32_swap(__float_as_uint(ze[s].y), __float_as_uint(zo[s].y), false, false);
-            const C2 E = C2{__uint_as_float(sr.x), __uint_as_float(si.x)};
-            C2 t = C2{__uint_as_float(sr.y), __uint_as_float(si.y)};
-            if (k == 8) { t = cx_swap(t) * C2{1.f, -1.f}; }
-            else if (k > 0) { t = cx_mul<float>(t, W32C[2 * k], W32C[2 * k + 1]); }
-            ze[s] = E + t;
-            zo[s] = E - t;
-        }
+        // the column's 32-point transform, in registers: X[k1] in ze[slot16(k1)], X[k1 + 16] in zo[slot16(k1)]
+        dft32f(ze, zo);
         R4096_STAMP(0);
         R4096_PRIO(1, 1);
 
@@ -489,26 +456,26 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
             if (q) { z = cx_mul<float>(z, RUN ? twl[64 * q + lane] : ta[q]); }
         }
 #endif
-        // first radix-2 stage of the 64-point transforms over n2: columns n2 and n2 + 32 sit 16 lanes
-        // apart; one swap of rows k1 and k1 + 16 leaves the even 16-lane groups with row k1
-        // (x = column n2, y = column n2 + 32) and the odd groups with row k1 + 16
+        // first radix-2 stage of the 64-point transforms over n2: columns n2 and n2 + 32 sit 32 lanes
+        // apart; one swap of rows k1 and k1 + 16 leaves the lower half-wave with row k1
+        // (x = column n2, y = column n2 + 32) and the upper one with row k1 + 16
         wave_sync();                                       // the previous frame's reads of the tile are done
         {
-            // tile row 2 k1 + parity; column n2 % 32 = 2 j16 + up is kept at position j16 + 16 up
-            C2 *dst = ex + (32 * hi16) * R4096_PITCH + j16 + 16 * up;
+            // tile row r = k1 + 32 parity, column n2 % 32 at its own position
+            C2 *dst = ex + (16 * hh2) * R4096_PITCH + jj;
 #pragma unroll
             for (int k1 = 0; k1 < 16; ++k1) {
                 const C2 lo = ze[slot16(k1)], hi = zo[slot16(k1)];
-                const u2v sr = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo.x), __float_as_uint(hi.x), false, false);
-                const u2v si = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo.y), __float_as_uint(hi.y), false, false);
+                const u2v sr = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo.x), __float_as_uint(hi.x), false, false);
+                const u2v si = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo.y), __float_as_uint(hi.y), false, false);
                 const C2 x = C2{__uint_as_float(sr.x), __uint_as_float(si.x)};
                 const C2 y = C2{__uint_as_float(sr.y), __uint_as_float(si.y)};
-                dst[(2 * k1) * R4096_PITCH] = x + y;
-                dst[(2 * k1 + 1) * R4096_PITCH] = cx_mul<float>(x - y, wl);
+                dst[k1 * R4096_PITCH] = x + y;
+                dst[(32 + k1) * R4096_PITCH] = cx_mul<float>(x - y, wl);
             }
         }
         wave_sync();
-        // where the next frame lies; its first loads go out now, under pass 2
+        // where the next frame lies; its loads go out now, under pass 2
         bool more;
         Where nxt;
         if constexpr (RUN) {
@@ -519,18 +486,18 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
 #if R4096_LOCKSTEP
             if ((iter++ & (R4096_LOCK_EVERY - 1)) == 0) { __builtin_amdgcn_s_barrier(); }   // the workgroup's 8 waves request neighbouring frames together
 #endif
-            if (nxt.inside) { load_inside(nxt, 0, 16); }
+            if (nxt.inside) { load_inside(nxt); }
         }
         R4096_STAMP(1);
 
-        // ---------------- pass 2: the lane's row (k1, parity): 32-point FFT ----------------
+        // ---------------- pass 2: the lane's row r = lane: 32-point FFT over the 32 columns ----------------
         {
-            const C2 *row = ex + trow * R4096_PITCH;
+            const C2 *row = ex + lane * R4096_PITCH;
 #pragma unroll
-            for (int m = 0; m < 16; ++m) { ze[m] = row[m]; zo[m] = row[16 + m]; }   // even / odd columns
+            for (int m = 0; m < 16; ++m) { ze[m] = row[2 * m]; zo[m] = row[2 * m + 1]; }   // even / odd columns
         }
         R4096_PRIO(1, 0);
-        dft32c(ze, zo);
+        dft32f(ze, zo);
         R4096_STAMP(2);
         R4096_PRIO(2, 1);
         wave_sync();                                       // every lane has its row: the tile is free
@@ -543,16 +510,15 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         wave_sync();
         R4096_STAMP(3);
         R4096_STAMP(4);
-
         // ---------------- split + power + store: the lane's bins k = r + 64 a, a < 16, and 2048 - k ----------------
         float *y = Y + (RUN ? (long long)run_b * a.Wy + run_w0 + tpos : cur.row) * (CPLX ? 2 * F : F);
         const C2 *zpart = ex + pslot;                                      // Z[2048 - k] at zpart[15 - a]
-        float *yf = y + (CPLX ? 2 : 1) * rho, *yr = y + (CPLX ? 2 : 1) * (M - rho);
+        float *yf = y + (CPLX ? 2 : 1) * lane, *yr = y + (CPLX ? 2 : 1) * (M - lane);
         [[maybe_unused]] C2 cu = C2{0.f, 0.f};
         if constexpr (CPLX) {
             // the rotation of the run form undone: bin k times i^(ROT k) = i^(ROT r), bin 2048 - k times its conjugate
             constexpr int RC = RUN ? ROT : 0;
-            const int e = (RC * rho) & 3;
+            const int e = (RC * lane) & 3;
             const float sc = a.cscale;
             cu = C2{e == 0 ? sc : (e == 2 ? -sc : 0.f), e == 1 ? sc : (e == 3 ? -sc : 0.f)};
         }
@@ -579,17 +545,23 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
                     if constexpr (RC == 0) { u = (A + Tw) * C2{cu.x, cu.x}; v = (A - Tw) * C2{cu.x, -cu.x}; }
                     else { u = cx_mul<float>(A + Tw, cu); v = cx_mul<float>(A - Tw, cu) * C2{1.f, -1.f}; }
                     if (aa == 0) { u.y = (lane == 0) ? 0.f : u.y; v.y = (lane == 0) ? 0.f : v.y; }   // bins 0 and 2048
-                    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
-                    *reinterpret_cast<f2u *>(yf + 128 * aa) = f2u{u.x, u.y};
-                    *reinterpret_cast<f2u *>(yr - 128 * aa) = f2u{v.x, v.y};
+                    *reinterpret_cast<float2_u *>(yf + 128 * aa) = float2_u{u.x, u.y};
+                    *reinterpret_cast<float2_u *>(yr - 128 * aa) = float2_u{v.x, v.y};
                 } else {
-                    p[c] = cx_norm<float>(A + Tw); q[c] = cx_norm<float>(A - Tw);
+                    p[c] = norm2(A + Tw); q[c] = norm2(A - Tw);
                 }
             }
             if constexpr (CPLX) { continue; }
             if (EPI) { power_epilogue_n(p, a.epi); power_epilogue_n(q, a.epi); }
 #if R4096_ABLATE & 1
             asm volatile("" :: "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]));
+            if (a.N == -12345)
+#endif
+#if R4096_HACK & 4
+            {   // timing only: the same bytes as four-value stores, at the wrong places
+                *reinterpret_cast<float4_u *>(y + 4 * lane + 256 * g) = float4_u{p[0], p[1], p[2], p[3]};
+                *reinterpret_cast<float4_u *>(y + 1025 + 4 * lane + 256 * g) = float4_u{q[0], q[1], q[2], q[3]};
+            }
             if (a.N == -12345)
 #endif
             {
@@ -613,10 +585,9 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
             const C2 zmid = ex[0];
             if constexpr (CPLX) {
                 // bin 1024 is 2 conj Z_1024 (times i^(ROT 1024) = 1)
-                typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
-                *reinterpret_cast<f2u *>(y + 2048) = f2u{2.0f * a.cscale * zmid.x, -2.0f * a.cscale * zmid.y};
+                *reinterpret_cast<float2_u *>(y + 2048) = float2_u{2.0f * a.cscale * zmid.x, -2.0f * a.cscale * zmid.y};
             }
-            float p = 4.0f * cx_norm<float>(zmid);
+            float p = 4.0f * norm2(zmid);
             if (EPI) { p = power_epilogue(p, a.epi); }
 #if R4096_ABLATE & 1
             asm volatile("" :: "v"(p));
@@ -648,7 +619,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
             if (lane == 0) { took = __hip_atomic_fetch_add(a.take + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
             open_run(fid);
             load_run_head(fid);
-            asm volatile("" : "+v"(took) : "v"(pre[3].w), "v"(pre[7].w), "v"(pre[11].w), "v"(pre[15].w));
+            asm volatile("" : "+v"(took) : "v"(pre[7].y), "v"(pre[15].y), "v"(pre[23].y), "v"(pre[31].y));
             const int nrun = f_lo + fstride + (int)__builtin_amdgcn_readfirstlane(took);
             tpos = 0;
             while (frame(rot<0>{}) && frame(rot<1>{}) && frame(rot<2>{}) && frame(rot<3>{})) { }
@@ -681,7 +652,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
             if (lane == 0) { took = __hip_atomic_fetch_add(a.take + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
             open_run(fid);
             load_run_head(fid);
-            asm volatile("" : "+v"(took) : "v"(pre[3].w), "v"(pre[7].w), "v"(pre[11].w), "v"(pre[15].w));
+            asm volatile("" : "+v"(took) : "v"(pre[7].y), "v"(pre[15].y), "v"(pre[23].y), "v"(pre[31].y));
             const int nrun = f_lo + fstride + (int)__builtin_amdgcn_readfirstlane(took);
             tpos = 0;
             while (frame(rot<0>{}) && frame(rot<1>{}) && frame(rot<2>{}) && frame(rot<3>{})) { }

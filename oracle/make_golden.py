@@ -41,6 +41,48 @@ def chain_cases():
     ]
 
 
+FLAG_CASES = ("base", "oddL", "hop_gt_L", "N_eq_L", "tiny")
+
+
+def flags_fixture():
+    """ref_chain_flags_{s,d}.npz: the amp / lg outputs of stft.  c/stft.c:86-95 applies sqrtf / logf / logf(sqrtf())
+    to the finished power row; the reference's own compiled pow_compress_s/_d (c/pow_compress.c:28-47) does exactly
+    that for (p, preg) = (0.5, 0) / (0, 0) / one after the other, so its outputs on the executed chain's power rows
+    are the reference's amp / lg rows.  Inputs are the cases of ref_chain_*.npz (same seeds)."""
+    assert O.ref() is not None, "oracle/_ref/libdspref.so missing (make -C oracle)"
+    for dt, tag in ((np.float32, "s"), (np.float64, "d")):
+        d = {}
+        for ci, (name, N, L, stp, nfft, wname) in enumerate(chain_cases()):
+            if name not in FLAG_CASES:
+                continue
+            rng = np.random.default_rng(1000 + ci)
+            x = rng.standard_normal(N).astype(dt)
+            h = O.ref_window(wname, L, dt)
+            d[f"{name}.x"] = x
+            d[f"{name}.win"] = h
+            d[f"{name}.params"] = np.array([N, L, stp, nfft], dtype=np.int64)
+            for snip in (0, 1):
+                if snip and L > N:
+                    continue
+                rc, wu = O.ref_window_univar(x, h, stp, snip)
+                assert rc == 0
+                rc, z = O.ref_fft_rad2(wu, nfft)
+                assert rc == 0
+                rc, p = O.ref_fft_power(z)
+                assert rc == 0
+                rc, a = O.pow_compress(p, 0.5, 0.0, use_ref=True)
+                assert rc == 0
+                rc, lg = O.pow_compress(p, 0.0, 0.0, use_ref=True)
+                assert rc == 0
+                rc, al = O.pow_compress(a, 0.0, 0.0, use_ref=True)
+                assert rc == 0
+                d[f"{name}.snip{snip}.power"] = p
+                d[f"{name}.snip{snip}.amp"] = a
+                d[f"{name}.snip{snip}.lg"] = lg
+                d[f"{name}.snip{snip}.amplg"] = al
+        np.savez_compressed(os.path.join(OUT, f"ref_chain_flags_{tag}.npz"), **d)
+
+
 def main():
     assert O.ref() is not None, "oracle/_ref/libdspref.so missing (make -C oracle)"
     os.makedirs(OUT, exist_ok=True)
@@ -196,8 +238,12 @@ def main():
             d[f"aw.dim0.col{col}"] = np.ascontiguousarray(y0)
             d[f"aw.dim1.col{col}"] = np.ascontiguousarray(y1)
         np.savez_compressed(os.path.join(OUT, f"ref_misc_{tag}.npz"), **d)
+    flags_fixture()
     print("wrote", sorted(os.listdir(OUT)))
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "flags":      # only the amp / lg fixtures (the others stay as committed)
+        flags_fixture()
+    else:
+        main()

@@ -3,11 +3,13 @@ oracle on the same seeded inputs, and against the fixtures made from executed re
 
 Tolerance of the path (stated once, used everywhere): per-frame-normalised max error
     max_f |Y - Yref| / max_f |Yref|  <=  1e-5 (float32), 1e-12 (float64)
-for power and amplitude outputs.  Log outputs are compared after exp() with the same bound (an
+for power and amplitude outputs.  Log outputs are compared twice: after exp() with the same bound (an
 element-wise bound in the log domain is meaningless on bins that are 1e-12 of the frame maximum, and
 a bin that is pure rounding residue, such as DC after mean removal, may be exactly 0 -> -inf in one
-implementation and 1e-12 of the maximum in the other); log of an all-zero frame must be -inf
-(test_log_of_silence_is_minus_inf).  Copies (framing) are bit-exact.
+implementation and 1e-12 of the maximum in the other), and in the log domain itself on the bins that
+reach LOG_FLOOR = 1e-3 of their frame's maximum, where an error of tol * max in the value is an
+absolute error of at most tol / LOG_FLOOR in its logarithm: 1e-2 (float32) / 1e-9 (float64); log of
+an all-zero frame must be -inf (test_log_of_silence_is_minus_inf).  Copies (framing) are bit-exact.
 """
 import os
 
@@ -25,11 +27,30 @@ def D():
     return dsp_amd
 
 
+LOG_FLOOR = 1e-3
+
+
+def check_log_domain(Y, Yref, tol):
+    """Absolute error of log outputs on the bins within LOG_FLOOR of their frame's maximum (log of the value or of its
+    square root alike: the bound on the logarithm of a power is twice that of its root, the larger one is used)."""
+    Y = Y.astype(np.float64).reshape(-1, Y.shape[-1])
+    Yref = Yref.astype(np.float64).reshape(-1, Yref.shape[-1])
+    with np.errstate(invalid="ignore"):
+        top = np.max(np.where(np.isfinite(Yref), Yref, -np.inf), axis=-1, keepdims=True)
+        loud = np.isfinite(Yref) & (Yref >= top + np.log(LOG_FLOOR))
+    if not loud.any():
+        return 0.0
+    err = float(np.max(np.abs(Y[loud] - Yref[loud])))
+    assert err <= tol / LOG_FLOOR, f"log-domain error {err:.3e} > {tol / LOG_FLOOR:.1e} on bins >= {LOG_FLOOR} of the frame maximum"
+    return err
+
+
 def check_spec(O, Y, Yref, amp=False, lg=False, tol=None):
     assert Y.shape == Yref.shape and Y.dtype == Yref.dtype
     tol = TOL[Y.dtype] if tol is None else tol
     if lg:
         assert not np.any(np.isposinf(Y)) and not np.any(np.isposinf(Yref))
+        check_log_domain(Y, Yref, tol)
         with np.errstate(over="ignore"):
             Y = np.exp(Y.astype(np.float64))
             Yref = np.exp(Yref.astype(np.float64))
@@ -39,6 +60,36 @@ def check_spec(O, Y, Yref, amp=False, lg=False, tol=None):
     err = O.normalised_err(Y, Yref)
     assert err <= tol, f"normalised error {err:.3e} > {tol:.1e}"
     return err
+
+
+@pytest.mark.parametrize("tag", ["s", "d"])
+def test_stft_amp_lg_against_reference_fixtures(O, D, tag):
+    """stft with -a / -l / both against rows made by EXECUTED reference code: the reference's chain for the power
+    (window_univar -> fft_rad2 -> fft_power) followed by its compiled pow_compress with (p, preg) = (0.5, 0), (0, 0)
+    and one after the other, which is what c/stft.c:86-95 does to a power row (sqrtf, logf, logf(sqrtf())).  The
+    power rows of the fixture carry the error of the reference's own radix-2 FFT (3e-6 / 2e-14 of the frame maximum),
+    so: amplitude rows on the bins >= 1e-3 of the frame's largest power within err_p / (2 sqrt(1e-3)) of the largest
+    amplitude, log rows there within err_p / 1e-3 absolute."""
+    g = load_golden(f"ref_chain_flags_{tag}.npz")
+    perr = {"s": 3e-6, "d": 2e-14}[tag] + TOL[g["base.x"].dtype]
+    for name in ("base", "oddL", "hop_gt_L", "N_eq_L", "tiny"):
+        x, win = g[f"{name}.x"], g[f"{name}.win"]
+        N, L, stp, nfft = (int(v) for v in g[f"{name}.params"])
+        for snip in (0, 1):
+            if f"{name}.snip{snip}.power" not in g:
+                continue
+            P = g[f"{name}.snip{snip}.power"].astype(np.float64)
+            loud = P >= LOG_FLOOR * P.max(axis=-1, keepdims=True)
+            for key, amp, lg in (("amp", 1, 0), ("lg", 0, 1), ("amplg", 1, 1)):
+                R = g[f"{name}.snip{snip}.{key}"].astype(np.float64)
+                Y = D.stft(x, win, stp, nfft=nfft, snip_edges=bool(snip), amp=bool(amp), lg=bool(lg)).astype(np.float64)
+                assert Y.shape == R.shape
+                if lg:
+                    err = np.max(np.abs(Y[loud] - R[loud]))
+                    assert err <= perr / LOG_FLOOR, (name, snip, key, err)
+                else:
+                    err = np.max(np.abs(Y - R)[loud] / np.broadcast_to(R.max(axis=-1, keepdims=True), R.shape)[loud])
+                    assert err <= perr / (2 * np.sqrt(LOG_FLOOR)), (name, snip, key, err)
 
 
 def signal(seed, N, dt):

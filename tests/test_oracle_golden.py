@@ -140,3 +140,46 @@ def test_fft_oracle_against_reference_radix2(O, tag):
         assert rc == 0 and rc2 == 0
         assert np.max(np.abs(yr - yh)) <= 4 * np.finfo(yr.real.dtype).eps * np.max(np.abs(yh))
     assert O.fft(np.zeros((3, 9), np.float32), 1, 8)[0] == 1
+
+
+@pytest.mark.parametrize("tag", ["s", "d"])
+def test_amp_lg_branches_against_reference_pow_compress(O, tag):
+    """The amp / lg branches of stft (c/stft.c:86-95: sqrtf, logf, logf(sqrtf()) of the power row) pinned to executed
+    reference code: tests/golden/ref_chain_flags_*.npz holds the reference chain's power rows and what the reference's
+    compiled pow_compress_s/_d made of them with (p, preg) = (0.5, 0), (0, 0) and one after the other.
+    (1) the oracle's restatement of pow_compress gives the fixture's rows bit for bit from the fixture's power;
+    (2) the oracle's stft with the flags set is bit for bit that same function of the oracle's own power rows;
+    (3) directly: the oracle's flagged rows against the fixture's on the bins >= 1e-3 of the frame's largest power,
+        within what the 3e-6 / 2e-14 power error of the reference's radix-2 FFT allows there."""
+    g = load_golden(f"ref_chain_flags_{tag}.npz")
+    floor = 1e-3
+    for name in ("base", "oddL", "hop_gt_L", "N_eq_L", "tiny"):
+        x, win = g[f"{name}.x"], g[f"{name}.win"]
+        N, L, stp, nfft = (int(v) for v in g[f"{name}.params"])
+        for snip in (0, 1):
+            if f"{name}.snip{snip}.power" not in g:
+                continue
+            P = g[f"{name}.snip{snip}.power"]
+            with np.errstate(divide="ignore"):
+                rc, a = O.pow_compress(P, 0.5, 0.0)
+                assert rc == 0 and np.array_equal(a, g[f"{name}.snip{snip}.amp"])
+                rc, l = O.pow_compress(P, 0.0, 0.0)
+                assert rc == 0 and np.array_equal(l, g[f"{name}.snip{snip}.lg"])
+                rc, al = O.pow_compress(a, 0.0, 0.0)
+                assert rc == 0 and np.array_equal(al, g[f"{name}.snip{snip}.amplg"])
+                rc, Yp = O.stft(x, win, stp, nfft, snip)
+                assert rc == 0
+                want = {"amp": O.pow_compress(Yp, 0.5, 0.0)[1], "lg": O.pow_compress(Yp, 0.0, 0.0)[1]}
+                want["amplg"] = O.pow_compress(want["amp"], 0.0, 0.0)[1]
+            loud = P.astype(np.float64) >= floor * P.astype(np.float64).max(axis=-1, keepdims=True)
+            for key, amp, lg in (("amp", 1, 0), ("lg", 0, 1), ("amplg", 1, 1)):
+                rc, Y = O.stft(x, win, stp, nfft, snip, 0, amp, lg)
+                assert rc == 0
+                assert np.array_equal(Y, want[key]), (name, snip, key)
+                R = g[f"{name}.snip{snip}.{key}"].astype(np.float64)
+                Y = Y.astype(np.float64)
+                if lg:
+                    assert np.max(np.abs(Y[loud] - R[loud])) <= PTOL[tag] / floor
+                else:
+                    top = np.broadcast_to(R.max(axis=-1, keepdims=True), R.shape)
+                    assert np.max((np.abs(Y - R) / top)[loud]) <= PTOL[tag] / (2 * np.sqrt(floor))

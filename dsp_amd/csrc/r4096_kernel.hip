@@ -91,11 +91,14 @@ typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));   // 16-
 #ifndef R4096_NT_STORE
 #define R4096_NT_STORE 0        // 1: rows are stored with the non-temporal hint
 #endif
+#ifndef R4096_LOADPOS
+#define R4096_LOADPOS 0         // run form: where the next group's loads are issued: 0 = right after the window step, 1 = after the first transform, 2 = after the exchange
+#endif
 #ifndef R4096_TA_AHEAD
 #define R4096_TA_AHEAD 1        // 1: run form reads the twiddle stage's per-lane factors right after the window step
 #endif
 #ifndef R4096_HACK
-#define R4096_HACK 0          // timing experiments only (wrong results): bit 0 = split without the constant factor, bit 1 = twiddle stage without the second factor
+#define R4096_HACK 0          // timing experiments only (wrong results): bit 1 = twiddle stage without the second factor, bit 3 = rows at a pitch of 2048 values (every store instruction on a 256-byte boundary)
 #endif
 #ifndef R4096_STAMPS
 #define R4096_STAMPS 0          // diagnostic builds: 1 = per-phase s_memtime sums into g_r4096_stamps
@@ -113,10 +116,6 @@ __device__ unsigned long long g_r4096_stamps[2048 * 10];   // per wave: 8 phase 
 #else
 #define R4096_STAMP(i) do {} while (0)
 #endif
-
-// W64^k, k < 32, as (cos, -sin)(2 pi k / 64) pairs; indexed with compile-time
-// constants only, so they fold into the instructions as literals
-__device__ constexpr float W64C[64] = {1.000000000e+00f, -0.000000000e+00f, 9.951847196e-01f, -9.801714122e-02f, 9.807852507e-01f, -1.950903237e-01f, 9.569403529e-01f, -2.902846634e-01f, 9.238795042e-01f, -3.826834261e-01f, 8.819212914e-01f, -4.713967443e-01f, 8.314695954e-01f, -5.555702448e-01f, 7.730104327e-01f, -6.343932748e-01f, 7.071067691e-01f, -7.071067691e-01f, 6.343932748e-01f, -7.730104327e-01f, 5.555702448e-01f, -8.314695954e-01f, 4.713967443e-01f, -8.819212914e-01f, 3.826834261e-01f, -9.238795042e-01f, 2.902846634e-01f, -9.569403529e-01f, 1.950903237e-01f, -9.807852507e-01f, 9.801714122e-02f, -9.951847196e-01f, 6.123234263e-17f, -1.000000000e+00f, -9.801714122e-02f, -9.951847196e-01f, -1.950903237e-01f, -9.807852507e-01f, -2.902846634e-01f, -9.569403529e-01f, -3.826834261e-01f, -9.238795042e-01f, -4.713967443e-01f, -8.819212914e-01f, -5.555702448e-01f, -8.314695954e-01f, -6.343932748e-01f, -7.730104327e-01f, -7.071067691e-01f, -7.071067691e-01f, -7.730104327e-01f, -6.343932748e-01f, -8.314695954e-01f, -5.555702448e-01f, -8.819212914e-01f, -4.713967443e-01f, -9.238795042e-01f, -3.826834261e-01f, -9.569403529e-01f, -2.902846634e-01f, -9.807852507e-01f, -1.950903237e-01f, -9.951847196e-01f, -9.801714122e-02f};
 
 using C2 = cx<float>;
 
@@ -408,17 +407,21 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         }
         R4096_STAMP(6);
         R4096_PRIO(4, 0);
-        // RUN: the stream moves on by one group, whose loads go out now, into the registers of the
-        // group that the next frame no longer holds
-        if constexpr (RUN) {
-            if (tpos + 1 < run_len) {
-                const Group q = find_group(run_b, run_w0, tpos + 4);
-                fetch_group(q, ROT);
+        // RUN: the stream moves on by one group, whose loads go out into the registers of the group that the next
+        // frame no longer holds
+        auto next_group = [&]() __attribute__((always_inline)) {
+            if constexpr (RUN) {
+                if (tpos + 1 < run_len) {
+                    const Group q = find_group(run_b, run_w0, tpos + 4);
+                    fetch_group(q, ROT);
+                }
             }
-        }
+        };
+        if (R4096_LOADPOS == 0) { next_group(); }
         R4096_STAMP(7);
         // the column's 32-point transform, in registers: X[k1] in ze[slot16(k1)], X[k1 + 16] in zo[slot16(k1)]
         dft32f(ze, zo);
+        if (R4096_LOADPOS == 1) { next_group(); }
         R4096_STAMP(0);
         R4096_PRIO(1, 1);
 
@@ -475,6 +478,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
             }
         }
         wave_sync();
+        if (R4096_LOADPOS == 2) { next_group(); }
         // where the next frame lies; its loads go out now, under pass 2
         bool more;
         Where nxt;
@@ -511,9 +515,14 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         R4096_STAMP(3);
         R4096_STAMP(4);
         // ---------------- split + power + store: the lane's bins k = r + 64 a, a < 16, and 2048 - k ----------------
+#if R4096_HACK & 8
+        // timing only: rows at a pitch of 2048 values, every store instruction on a 256-byte boundary
+        float *y = Y + (RUN ? (long long)run_b * a.Wy + run_w0 + tpos : cur.row) * 2048;
+#else
         float *y = Y + (RUN ? (long long)run_b * a.Wy + run_w0 + tpos : cur.row) * (CPLX ? 2 * F : F);
+#endif
         const C2 *zpart = ex + pslot;                                      // Z[2048 - k] at zpart[15 - a]
-        float *yf = y + (CPLX ? 2 : 1) * lane, *yr = y + (CPLX ? 2 : 1) * (M - lane);
+        float *yf = y + (CPLX ? 2 : 1) * lane, *yr = y + (CPLX ? 2 : 1) * (M - ((R4096_HACK & 8) ? 1 : 0) - lane);
         [[maybe_unused]] C2 cu = C2{0.f, 0.f};
         if constexpr (CPLX) {
             // the rotation of the run form undone: bin k times i^(ROT k) = i^(ROT r), bin 2048 - k times its conjugate
@@ -522,61 +531,68 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
             const float sc = a.cscale;
             cu = C2{e == 0 ? sc : (e == 2 ? -sc : 0.f), e == 1 ? sc : (e == 3 ? -sc : 0.f)};
         }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float p[4], q[4];
+        // Four pairs at a time, stage by stage (no instruction feeds the one right behind it).  The factor of the
+        // split, -i W4096^k = (-i W4096^r) W64^a, is taken in two parts: the constant W64^a in folded form (fft16.h:
+        // a sum before the product with the lane's factor, a real factor and a power of i inside the last additions).
+        auto pairs4 = [&](auto g_c) __attribute__((always_inline)) {
+            constexpr int G = decltype(g_c)::value;
+            constexpr TwF f[4] = {twf_n(4 * G, 64), twf_n(4 * G + 1, 64), twf_n(4 * G + 2, 64), twf_n(4 * G + 3, 64)};
+            C2 A[4], B[4], t[4], P[4], Q[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const int aa = 4 * g + c;
+                const int aa = 4 * G + c;
                 const C2 z = ze[slot16(aa)];
                 C2 zm = zpart[15 - aa];
                 if (aa == 0) { zm = (lane == 0) ? z : zm; }                // bin 0 pairs with itself
-                const C2 A = cx_add_conj<float>(z, zm);
-                C2 B = cx_sub_conj<float>(z, zm);
-                // -i W4096^k B with W4096^k = W4096^r W64^a
-#if !(R4096_HACK & 1)
-                if (aa > 0) { B = cx_mul<float>(B, W64C[2 * aa], W64C[2 * aa + 1]); }
-#endif
-                const C2 Tw = cx_mul<float>(B, ow);
-                if constexpr (CPLX) {
-                    // X_k = A + T, X_(2048-k) = conj(A - T)
-                    constexpr int RC = RUN ? ROT : 0;
+                A[c] = cx_add_conj<float>(z, zm);
+                B[c] = cx_sub_conj<float>(z, zm);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { if (f[c].t != 0.0) { B[c] = cx_pre<float>(B[c], (float)f[c].t); } }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { t[c] = cx_mul_first<float>(B[c], ow); }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { B[c] = cx_mul_second<float>(B[c], ow, t[c]); }
+            // X_k = A + T, X_(2048-k) = conj(A - T), T = sig i^m B
+#define R4096_PQ(c) P[c] = cx_axpy_i<float, f[c].m>(A[c], (float)f[c].sig, B[c]); Q[c] = cx_axpy_i<float, f[c].m + 2>(A[c], (float)f[c].sig, B[c]);
+            R4096_PQ(0) R4096_PQ(1) R4096_PQ(2) R4096_PQ(3)
+#undef R4096_PQ
+            if constexpr (CPLX) {
+                constexpr int RC = RUN ? ROT : 0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int aa = 4 * G + c;
                     C2 u, v;
-                    if constexpr (RC == 0) { u = (A + Tw) * C2{cu.x, cu.x}; v = (A - Tw) * C2{cu.x, -cu.x}; }
-                    else { u = cx_mul<float>(A + Tw, cu); v = cx_mul<float>(A - Tw, cu) * C2{1.f, -1.f}; }
+                    if constexpr (RC == 0) { u = P[c] * C2{cu.x, cu.x}; v = Q[c] * C2{cu.x, -cu.x}; }
+                    else { u = cx_mul<float>(P[c], cu); v = cx_mul<float>(Q[c], cu) * C2{1.f, -1.f}; }
                     if (aa == 0) { u.y = (lane == 0) ? 0.f : u.y; v.y = (lane == 0) ? 0.f : v.y; }   // bins 0 and 2048
                     *reinterpret_cast<float2_u *>(yf + 128 * aa) = float2_u{u.x, u.y};
                     *reinterpret_cast<float2_u *>(yr - 128 * aa) = float2_u{v.x, v.y};
-                } else {
-                    p[c] = norm2(A + Tw); q[c] = norm2(A - Tw);
                 }
-            }
-            if constexpr (CPLX) { continue; }
-            if (EPI) { power_epilogue_n(p, a.epi); power_epilogue_n(q, a.epi); }
-#if R4096_ABLATE & 1
-            asm volatile("" :: "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]));
-            if (a.N == -12345)
-#endif
-#if R4096_HACK & 4
-            {   // timing only: the same bytes as four-value stores, at the wrong places
-                *reinterpret_cast<float4_u *>(y + 4 * lane + 256 * g) = float4_u{p[0], p[1], p[2], p[3]};
-                *reinterpret_cast<float4_u *>(y + 1025 + 4 * lane + 256 * g) = float4_u{q[0], q[1], q[2], q[3]};
-            }
-            if (a.N == -12345)
-#endif
-            {
+            } else {
+                float p[4], q[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-#if R4096_NT_STORE
-                    __builtin_nontemporal_store(p[c], yf + 64 * (4 * g + c));
-                    __builtin_nontemporal_store(q[c], yr - 64 * (4 * g + c));
-#else
-                    yf[64 * (4 * g + c)] = p[c];
-                    yr[-64 * (4 * g + c)] = q[c];
+                for (int c = 0; c < 4; ++c) { p[c] = norm2(P[c]); q[c] = norm2(Q[c]); }
+                if (EPI) { power_epilogue_n(p, a.epi); power_epilogue_n(q, a.epi); }
+#if R4096_ABLATE & 1
+                asm volatile("" :: "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]));
+                if (a.N == -12345)
 #endif
+                {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+#if R4096_NT_STORE
+                        __builtin_nontemporal_store(p[c], yf + 64 * (4 * G + c));
+                        __builtin_nontemporal_store(q[c], yr - 64 * (4 * G + c));
+#else
+                        yf[64 * (4 * G + c)] = p[c];
+                        yr[-64 * (4 * G + c)] = q[c];
+#endif
+                    }
                 }
             }
-        }
+        };
+        pairs4(rot<0>{}); pairs4(rot<1>{}); pairs4(rot<2>{}); pairs4(rot<3>{});
         {
             // bin 1024 = row 0, k' = 16: the first value lane 0 left in the second exchange.  It pairs with itself (Z
             // holds half values).  Every lane stores the same value to the same address: a store under

@@ -178,7 +178,10 @@ def stft_multi_dev(x_blocks, wins, stp=160, snip_edges=False, mn0=False, amp=Fal
     xp = (vp * ngpu)(*[xb.data_ptr() for xb in x_blocks])
     wp = (vp * ngpu)(*[w.data_ptr() for w in wins])
     devs = (C.c_int * ngpu)(*devices)
-    torch.cuda.synchronize()
+    # the entry point launches on streams of its own on every GPU of the list, which are not ordered with torch's:
+    # whatever still produces the blocks and the windows there (copies, earlier kernels) has to be finished first
+    for dv in sorted(set(devices)):
+        torch.cuda.synchronize(dv)
     rc = getattr(lib(), f"dsp_stft_multi_dev_{s}")(C.cast(yp, vp), C.cast(xp, vp), C.cast(wp, vp), vp(y_all.data_ptr() if gather else 0), B, N, N, L,
                                                    nfft, stp, int(bool(snip_edges)), int(bool(mn0)), int(bool(amp)), int(bool(lg)),
                                                    C.cast(devs, vp), ngpu)
@@ -489,6 +492,8 @@ def stft_cplx_dev(x, win, stp=160, snip_edges=False, sc=False, nfft=None, out=No
     single = x.dim() == 1
     if single:
         x = x[None, :]
+    if not x.is_cuda or x.dim() != 2:
+        raise ValueError("x must be a device tensor [B, N] or [N]")
     if x.stride(1) != 1:
         x = x.contiguous()
     s = _torch_sfx(x)
@@ -505,8 +510,9 @@ def stft_cplx_dev(x, win, stp=160, snip_edges=False, sc=False, nfft=None, out=No
         if out.dtype != cdt or out.device != x.device:
             raise ValueError("stft_cplx_dev: out must be a complex tensor of x's precision on x's device")
     ldx = x.stride(0) if B > 1 else N
-    rc = getattr(lib(), f"dsp_stft_cplx_batch_dev_{s}")(C.c_void_p(out.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(win.data_ptr()),
-                                                        B, N, ldx, L, nfft, stp, int(bool(snip_edges)), int(bool(sc)), _stream_ptr(x))
+    with torch.cuda.device(x.device):                     # the library takes its tables from, and launches on, the current device
+        rc = getattr(lib(), f"dsp_stft_cplx_batch_dev_{s}")(C.c_void_p(out.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(win.data_ptr()),
+                                                            B, N, ldx, L, nfft, stp, int(bool(snip_edges)), int(bool(sc)), _stream_ptr(x))
     _check(rc, f"dsp_stft_cplx_batch_dev_{s}")
     return out[0] if single else out
 

@@ -505,6 +505,9 @@ int run_fused_host_streamed(const char *fn, int dev, T *Y, const T *X, const T *
                 if (!htbl && d.edge == 0) {
                     if (first < 0) { hi = std::max(hi, -first); }                                  // sample -n-1 for n < 0
                     if (last_end > (long long)N) { lo = std::min(lo, 2 * (long long)N - last_end); } // sample 2N-1-n for n >= N
+                    // The span-staging kernels gather a whole step's span once it crosses the end of the signal, samples
+                    // behind the last window included (unused, but read): they reflect down to 2N - (last_end + slack).
+                    if (last_end + slack > (long long)N) { lo = std::min(lo, 2 * (long long)N - (last_end + slack)); }
                 }
                 lo = std::max(0ll, std::min(lo, (long long)N)) & ~3ll;     // (a multiple of 16 bytes: loads keep the alignment they have in one launch)
                 hi = std::max(lo, std::min(hi, (long long)N));
@@ -863,6 +866,35 @@ int stft_multi_dev(const char *fn, T *const *Y_dev, const T *const *X_dev, const
     const size_t F = nfft / 2 + 1;
     const int dev0 = devices ? devices[0] : 0;
     const int keep = tl_device;
+    int prev = 0, ndev = 0;
+    HIPCHK(fn, hipGetDevice(&prev));                     // the calling thread's device, current again on every way out
+    HIPCHK(fn, hipGetDeviceCount(&ndev));
+    for (int g = 0; g < ngpu; ++g) {
+        const int dv = devices ? devices[g] : g;
+        if (dv < 0 || dv >= ndev) { fprintf(stderr, "error in %s: device %d not available\n", fn, dv); return 1; }
+    }
+    if (Y_all_dev) {
+        // the gather copies a block from its GPU straight into devices[0]'s memory: that needs peer access, asked
+        // for here and reported when the machine does not grant it (no silent detour through the host)
+        for (int g = 0; g < ngpu; ++g) {
+            const int dv = devices ? devices[g] : g;
+            if (dv == dev0) { continue; }
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, dv, dev0) != hipSuccess || !can) {
+                fprintf(stderr, "error in %s: device %d has no peer access to device %d (needed to gather the blocks)\n", fn, dv, dev0);
+                (void)hipSetDevice(prev);
+                return 1;
+            }
+            hipError_t e = hipSetDevice(dv);
+            if (e == hipSuccess) { e = hipDeviceEnablePeerAccess(dev0, 0); }
+            if (e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); e = hipSuccess; }
+            if (e != hipSuccess) {
+                fprintf(stderr, "error in %s: hip call failed (peer access of device %d to device %d): %s\n", fn, dv, dev0, hipGetErrorString(e));
+                (void)hipSetDevice(prev);
+                return 1;
+            }
+        }
+    }
     std::vector<hipStream_t> streams(ngpu, nullptr);
     int rc = 0;
     for (int g = 0; g < ngpu && !rc; ++g) {
@@ -888,7 +920,7 @@ int stft_multi_dev(const char *fn, T *const *Y_dev, const T *const *X_dev, const
         (void)hipStreamDestroy(streams[g]);
     }
     tl_device = keep;
-    if (keep >= 0) { (void)hipSetDevice(keep); }
+    (void)hipSetDevice(prev);
     return rc;
 }
 

@@ -221,6 +221,20 @@ __device__ __forceinline__ void bfly_tw(cx<T> &e, cx<T> &o)
     e = lo;
 }
 
+// the 16-point transform the fused kernels use: folded twiddles unless DSP_FOLDED_DFT16 is 0 (A/B builds)
+#ifndef DSP_FOLDED_DFT16
+#define DSP_FOLDED_DFT16 1
+#endif
+template <typename T, int NZ = 16>
+__device__ __forceinline__ void dft16x(cx<T> (&z)[16])
+{
+#if DSP_FOLDED_DFT16
+    dft16f<T, NZ>(z);
+#else
+    dft16c<T, NZ>(z);
+#endif
+}
+
 constexpr int R512_EXF = 16 * 17;   // complex slots per frame in the exchange region (row pitch 17)
 
 }  // namespace dsp

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(64 * r256_waves<T>(), sizeof(T) == 4 ? 2 : 1) void 
                 }
             }
         }
-        dft16c<T, NR>(zz);
+        dft16x<T, NR>(zz);
         wave_sync();                                       // all lanes have read the span
         // The slot takes the next step's span.  The reads of pass 1 must have RETURNED before the first load into
         // the slot is issued (the compiler may sink their consumers, and with them its own wait, below the

@@ -427,7 +427,7 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
                 }
             }
         }
-        dft16c<T, NR>(zz);
+        dft16x<T, NR>(zz);
         const T *nxrow = xrow;
         if constexpr (TBL && !RING) {
             if (more) { nxrow = tbl_xrow(tvn); load_span(nxb, __builtin_amdgcn_readfirstlane(tvn)); }
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
 #pragma unroll
             for (int n2 = 0; n2 < 16; ++n2) { const T2 t = exf[n2]; zz[n2] = C{t.x, t.y}; }
         }
-        dft16c<T, 16>(zz);
+        dft16x<T, 16>(zz);
         R512F_STAMP(2);
 
         // ---- real-FFT split fused with power, in registers.  The lane holds Z[j + 16 k2] (halved);

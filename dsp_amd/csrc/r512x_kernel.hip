@@ -366,7 +366,7 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
             for (int k1 = 1; k1 < 16; ++k1) { const pair_a t = ttab[k1 * 16 + j]; twl[k1] = C{t.x, t.y}; }
             __builtin_amdgcn_sched_barrier(0);             // (the scheduler would sink the reads below the transform)
         }
-        dft16c<T, 16>(zz);
+        dft16x<T, 16>(zz);
         wave_sync();                                       // all lanes have read the span
         // The slot takes the next step's span.  The reads of pass 1 must have RETURNED before the first load into
         // the slot is issued (the compiler may sink their consumers, and with them its own wait, below the
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
 #pragma unroll
             for (int n2 = 0; n2 < 16; ++n2) { const pair_a t = exf[n2]; zz[n2] = C{t.x, t.y}; }
         }
-        dft16c<T, 16>(zz);
+        dft16x<T, 16>(zz);
 
         // ---- real-FFT split fused with power.  The lane holds Z[K] (halved), K = Q (j + 16 k2) + r, in
         // register k2.  Z[M - K] is, for r = 0: register 15 - k2 of lane (16 - j) % 16 (register (16 - k2) % 16

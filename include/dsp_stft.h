@@ -206,8 +206,10 @@ int dsp_stft_flt_set_mode (const int intended);
  * The first use of an nfft on a device builds its twiddle table (an allocation and a blocking copy; the first use
  * of a non-integral stft_flt framing likewise builds its table of frame starts); calls after that only enqueue.
  * Every entry point of this library returns, for a given signal, values that depend on that signal and the
- * arguments only: the host-pointer, batched, strided, multi-GPU and allocation-free forms give the same bits as
- * this one.  One exception: nfft 4096 with a full window and hop 1024 walks a signal in runs of 32 frames when the
+ * arguments only: the host-pointer, batched, strided and multi-GPU forms give the same bits as this one (the
+ * allocation-free form computes its twiddle tables on the device instead of taking the host's: the same values
+ * unless a table entry lies within 1e-16 of a rounding boundary, so equal bits in practice, the tolerance of the
+ * path by contract).  One exception: nfft 4096 with a full window and hop 1024 walks a signal in runs of 32 frames when the
  * batch has at least 4096 such runs and frame by frame when it has fewer; the two walks differ in the last bit, so
  * a signal transformed alone (few runs) and inside a large batch may differ by one ulp. */
 int dsp_stft_batch_dev_s (float *Y_dev, const float *X_dev, const float *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, void *stream);
@@ -218,8 +220,9 @@ int dsp_stft_batch_dev_d (double *Y_dev, const double *X_dev, const double *win_
  * power of two <= 4096 (any other nfft returns 1 with an error line).  It calls no hipMalloc / hipFree:
  * the twiddle tables and the work counters its kernels use live in one 33 KB array of the library's code
  * object (each device the library runs on holds its copy until the process ends).  The first call on a
- * device computes the tables with a kernel in `stream` and waits for that stream once; later calls only
- * enqueue.  Every call on a device shares that array: the counters are cleared in `stream` before each
+ * device computes the tables with a kernel in `stream` and waits for that stream once -- so the FIRST call on a
+ * device must be made outside a graph capture (a stream that is being captured cannot be waited for); later
+ * calls only enqueue and may be captured.  Every call on a device shares that array: the counters are cleared in `stream` before each
  * 4096-point launch, so calls that OVERLAP on one device (different streams) race; calls in one stream,
  * or one after another, do not.  Same arguments, output and error behaviour as dsp_stft_batch_dev_s. */
 int dsp_stft_batch_dev_noalloc_s (float *Y_dev, const float *X_dev, const float *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, void *stream);
@@ -267,7 +270,11 @@ int dsp_stft_flt_batch_d (double *Y, const double *X, const double *win, const s
  * dsp_stft_multi_dev_s/_d: X_dev[g], win_dev[g], Y_dev[g] are GPU g's input block, window and output block
  * (device memory of devices[g]); Y_all_dev, if not NULL, is memory of devices[0] for the whole Y[B][W][F], and
  * every block is copied into it over the GPU-to-GPU links as soon as it is complete (a block that already
- * lies there is not copied).  Both return when all work has finished. */
+ * lies there is not copied): that copy needs peer access of devices[g] to devices[0], which the call enables
+ * and, where the machine does not grant it, reports as an error (return 1) before any work starts.  The
+ * kernels run on streams of the call's own on every GPU, not ordered with any stream of the caller: whatever
+ * produces X_dev[g] and win_dev[g] must have finished on devices[g] before the call.  The calling thread's
+ * current device is the same after the call as before it.  Both return when all work has finished. */
 void dsp_shard_range (const size_t B, const size_t rank, const size_t world, size_t *lo, size_t *hi);
 int dsp_stft_multi_s (float *Y, const float *X, const float *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, const int *devices, const int ngpu);
 int dsp_stft_multi_d (double *Y, const double *X, const double *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, const int *devices, const int ngpu);

@@ -190,6 +190,26 @@ def test_stft_tool_matches_oracle(tools, O, tmp_path, dt):
 
 
 @gpu
+def test_stft_tool_on_the_reference_configuration(tools, O, tmp_path):
+    """The reference's own case through the tool, exactly: 10 s mono @ 16 kHz float32, 400-sample Hann window, hop 160
+    (the tool's default), nfft 512 = nextpow2(400), power spectrogram: 1000 x 257."""
+    rng = np.random.default_rng(16000)
+    x = (rng.standard_normal(160000) * 0.1).astype(np.float32)
+    import dsp_amd
+    win = dsp_amd.hann(400, np.float32)
+    xp, wp, yp = tmp_path / "x.npy", tmp_path / "w.npy", tmp_path / "y.npy"
+    np.save(xp, x); np.save(wp, win)
+    r = run([os.path.join(tools, "stft"), str(xp), str(wp), "-o", str(yp)])
+    assert r.returncode == 0, r.stderr
+    Y = np.load(yp)
+    assert Y.shape == (1000, 257) and Y.dtype == np.float32
+    rc, Yref = O.stft(x, win, 160, 512)
+    assert rc == 0
+    check(O, Y, Yref)
+    assert np.array_equal(Y, dsp_amd.stft(x, win, 160))          # the tool is the library call, nothing else
+
+
+@gpu
 def test_stft_tool_major_order_and_armadillo(tools, O, tmp_path):
     rng = np.random.default_rng(6)
     x = rng.standard_normal(5000).astype(np.float32)

@@ -945,6 +945,67 @@ def test_full_size_batch_1024_utterances(O, D):
         assert torch.equal(checksum(Y), ref)
 
 
+def test_full_size_share_of_sharded_batch_8192_utterances(O, D):
+    """One GPU's share of the sharded configuration (65 536 utterances over 8 GPUs): 8192 x 10 s @ 16 kHz float32,
+    Hann 400 / hop 160 / nfft 512: 5.2 GB in, 8.4 GB out, one launch.  Sampled signals against the oracle; the batch
+    cut into two launches, and into the eight blocks dsp_shard_range would give eight ranks, returns the same bits;
+    repeated launches return the same bits (exact checksum per signal)."""
+    import torch
+    B, N = 8192, 160000
+    g = torch.Generator(device="cuda").manual_seed(4321)
+    x = torch.randn((B, N), generator=g, device="cuda", dtype=torch.float32) * 0.1
+    win = torch.from_numpy(D.hann(400)).cuda()
+    Y = D.stft_dev(x, win, 160)
+    torch.cuda.synchronize()
+    assert tuple(Y.shape) == (B, 1000, 257)
+    for b in (0, 4095, 4096, 8191):
+        rc, Yref = O.stft(x[b].cpu().numpy(), win.cpu().numpy(), 160, 512, exact=False)
+        check_spec(O, Y[b].cpu().numpy(), Yref)
+
+    def checksum(t):
+        return t.view(torch.int32).to(torch.int64).sum(dim=(1, 2))
+    ref = checksum(Y)
+    part = torch.empty((B // 2, 1000, 257), device="cuda", dtype=torch.float32)
+    for h in range(2):
+        D.stft_dev(x[h * (B // 2):(h + 1) * (B // 2)], win, 160, out=part)
+        torch.cuda.synchronize()
+        assert torch.equal(part, Y[h * (B // 2):(h + 1) * (B // 2)])
+    del part
+    for r in range(8):
+        lo, hi = D.shard_range(B, r, 8)
+        blk = D.stft_dev(x[lo:hi], win, 160)
+        torch.cuda.synchronize()
+        assert torch.equal(checksum(blk), ref[lo:hi])
+        del blk
+    for _ in range(5):
+        D.stft_dev(x, win, 160, out=Y)
+        torch.cuda.synchronize()
+        assert torch.equal(checksum(Y), ref)
+
+
+def test_bench_two_rank_rehearsal_in_a_fresh_process():
+    """bench.py's N > 1 branch, started the way the driver starts it (python -m torch.distributed.run, one process per
+    rank), as a fresh child: two ranks on this one GPU over gloo (DSP_BENCH_REHEARSAL=1), the 1024-utterance workload so
+    that both ranks' batches fit beside each other.  The JSON line must carry n_gpus 2, the whole-job value and a gather
+    object without an error."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DSP_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29577", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+           "--workload", "utt1024x10s_f32_hann400_hop160_nfft512", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
+    assert d["value"] > 0 and abs(d["value"] - 2 * 1024 * 1000 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert isinstance(d.get("gather"), dict) and "error" not in d["gather"], d.get("gather")
+
+
 def test_full_size_chunks_equal_channels_alone(O, D, monkeypatch):
     """The multi-channel launches of the long-signal configurations: 64 and 8 channels of 1 h @ 16 kHz float64
     through stft_flt (Povey 400, hop 160.0, c0 200), 8 channels of 1 h @ 48 kHz float32 with nfft 4096 / hop 1024.
@@ -1440,6 +1501,26 @@ def test_stft_flt_reference_framing_head_and_tail(O, D):
                     rc, Yref = O.stft_flt(x[b].astype(np.float64), win.astype(np.float64), W, c0, stp, nfft, mn0, amp, lg, intended=False, exact=False)
                     assert rc == 0
                     check_spec(O, Y[b], Yref.astype(dt), amp, lg)
+
+
+def test_host_streamed_short_last_range(O, D):
+    """A long signal whose last range of frames holds only two frames (float32: ranges of 30 080 frames): the kernels that
+    stage a step's whole span then reflect samples from well before the range's own first sample; the staged range must
+    reach down to them.  Same bits as one launch over the signal on the device; the signal's last frames against the oracle."""
+    import torch
+    fw = 30080
+    W = 6 * fw + 2
+    N = W * 160 - 80
+    rng = np.random.default_rng(7)
+    x = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    win = D.hann(400, np.float32)
+    assert D.num_frames(N, 400, 160) == W
+    Yh = D.stft(x, win, 160)
+    Yd = D.stft_dev(torch.from_numpy(x).cuda()[None, :], torch.from_numpy(win).cuda(), 160)[0].cpu().numpy()
+    assert np.array_equal(Yh, Yd)
+    tail = 160 * 60 + (N % 160)
+    rc, Yref = O.stft(x[-tail:], win, 160, 512)
+    check_spec(O, Yh[-40:], Yref[-40:])
 
 
 def test_host_long_signal_streamed_by_frames(O, D):

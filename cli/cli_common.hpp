@@ -60,6 +60,69 @@ inline int open_output(const Diag &dg, const ArgSpec &ofile, Output &out)
     return 0;
 }
 
+// Where the signals of input 1 lie.  Without -d the input must be a vector (the reference's rule).  With -d the
+// input may be a matrix (R x C) transformed along axis d, every vector along that axis a signal: B signals of N samples,
+// signal b at X + b * ldx, its samples incx elements apart (the tensors' two major orders, reference
+// c/fft.fftw.r2hc.c:63-65: contiguous signals when d is the fastest axis, interleaved channels otherwise).
+struct Signals {
+    bool multi = false;
+    size_t B = 1, N = 0, ldx = 0, incx = 1;
+};
+
+inline int locate_signals(const Diag &dg, const TensorInfo &i1, const ArgSpec &dimopt, Signals &sg)
+{
+    if (dimopt.count == 0) {
+        if (!i1.isvec()) { return dg.fail("input 1 (X1) must be a vector"); }
+        sg.multi = false; sg.B = 1; sg.N = i1.N(); sg.ldx = i1.N(); sg.incx = 1;
+        return 0;
+    }
+    if (dimopt.ival < 0 || dimopt.ival > 1) { return dg.fail("dim must be in {0,1}"); }
+    if (!i1.ismat()) { return dg.fail("input 1 (X1) must be a matrix or a vector with -d"); }
+    const bool along_rows = dimopt.ival == 1;              // axis 1: every row is a signal
+    sg.multi = true;
+    sg.N = along_rows ? i1.C : i1.R;
+    sg.B = along_rows ? i1.R : i1.C;
+    const bool contiguous = along_rows == i1.isrowmajor();  // the transformed axis is the fastest one
+    if (contiguous) { sg.ldx = sg.N; sg.incx = 1; }
+    else { sg.ldx = 1; sg.incx = sg.B; }
+    return 0;
+}
+
+// Output header: frames contiguous, W x F for a row-major input and F x W for a column-major one (the same bytes);
+// with -d one such block per signal: B x W x F, or F x W x B.
+inline void size_output(const TensorInfo &i1, const Signals &sg, size_t W, size_t F, TensorInfo &o1)
+{
+    o1.F = i1.F; o1.T = i1.T; o1.colmajor = i1.colmajor;
+    if (!sg.multi) {
+        o1.ndim = 2;
+        o1.R = i1.isrowmajor() ? W : F;
+        o1.C = i1.isrowmajor() ? F : W;
+        o1.S = i1.S; o1.H = i1.H;
+    } else {
+        o1.ndim = 3;
+        o1.R = i1.isrowmajor() ? sg.B : F;
+        o1.C = W;
+        o1.S = i1.isrowmajor() ? F : sg.B;
+        o1.H = 1;
+    }
+}
+
+// --device / --ngpu: values or the reason they are unusable
+inline int device_options(const Diag &dg, const ArgSpec &devopt, const ArgSpec &ngpuopt, int &device, int &ngpu)
+{
+    device = -1; ngpu = 1;
+    if (devopt.count > 0) {
+        if (devopt.ival < 0 || devopt.ival > 63) { return dg.fail("device must be in [0 63]"); }
+        device = (int)devopt.ival;
+    }
+    if (ngpuopt.count > 0) {
+        if (ngpuopt.ival < 1 || ngpuopt.ival > 64) { return dg.fail("ngpu must be in [1 64]"); }
+        ngpu = (int)ngpuopt.ival;
+    }
+    if (device >= 0 && ngpu > 1) { return dg.fail("--device and --ngpu cannot be combined"); }
+    return 0;
+}
+
 inline bool read_payload(std::istream &is, void *dst, size_t nbytes)
 {
     char *p = static_cast<char *>(dst);

@@ -51,6 +51,9 @@ SIGNATURES = {
     "dsp_stft_flt_batch_dev_strided_d": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _sz, _d, _d, _int, _int, _int, _vp]),
     "dsp_stft_flt_batch_dev_s": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _f, _f, _int, _int, _int, _vp]),
     "dsp_stft_flt_batch_dev_d": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _d, _d, _int, _int, _int, _vp]),
+    "dsp_stft_batch_strided_s": (_int, _BHOST[:6] + [_sz] + _BHOST[6:]), "dsp_stft_batch_strided_d": (_int, _BHOST[:6] + [_sz] + _BHOST[6:]),
+    "dsp_stft_flt_batch_strided_s": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _sz, _f, _f, _int, _int, _int]),
+    "dsp_stft_flt_batch_strided_d": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _sz, _d, _d, _int, _int, _int]),
     "dsp_stft_batch_s": (_int, _BHOST), "dsp_stft_batch_d": (_int, _BHOST),
     "dsp_stft_flt_multi_s": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _f, _f, _int, _int, _int, _vp, _int]),
     "dsp_stft_flt_multi_d": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _d, _d, _int, _int, _int, _vp, _int]),

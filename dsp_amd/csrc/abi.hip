@@ -767,6 +767,62 @@ int with_dense_signals(const char *fn, const T *Xd, size_t B, size_t N, size_t l
     return rc;
 }
 
+// Host-pointer forms of the same (the tools' path for a multivariate file with interleaved channels): the whole
+// span of the tensor that holds the signals goes to the device as it lies, the signals are gathered there, the
+// spectrograms come back dense.  run(Yd, Xd, wd) enqueues the device-pointer form on the null stream.
+template <typename T, typename RunDev>
+int strided_host(const char *fn, T *Y, const T *X, const T *win, size_t B, size_t N, size_t ldx, size_t incx, size_t L, size_t y_elems, RunDev run)
+{
+    if (incx == 0) { fprintf(stderr, "error in %s: incx must be positive\n", fn); return 1; }
+    if (B == 0 || N == 0 || y_elems == 0) { return 0; }
+    int dev;
+    if (use_device(fn, dev)) { return 1; }
+    DevState &st = g_dev[dev];
+    std::lock_guard<std::mutex> lk(st.ws_mu);
+    const size_t span = (B - 1) * ldx + (N - 1) * incx + 1;
+    void *dx, *dy, *dw;
+    if (ws_reserve(fn, st, 0, span * sizeof(T), dx)) { return 1; }
+    if (ws_reserve(fn, st, 1, y_elems * sizeof(T), dy)) { return 1; }
+    if (ws_reserve(fn, st, 2, L * sizeof(T), dw)) { return 1; }
+    HIPCHK(fn, hipMemcpy(dx, X, span * sizeof(T), hipMemcpyHostToDevice));
+    HIPCHK(fn, hipMemcpy(dw, win, L * sizeof(T), hipMemcpyHostToDevice));
+    if (run((T *)dy, (const T *)dx, (const T *)dw)) { return 1; }
+    HIPCHK(fn, hipMemcpy(Y, dy, y_elems * sizeof(T), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+template <typename T>
+int stft_strided_host(const char *fn, T *Y, const T *X, const T *win, size_t B, size_t N, size_t ldx, size_t incx, size_t L, size_t nfft, size_t stp,
+                      int snip_edges, int mn0, int amp, int lg)
+{
+    if (incx == 1) {
+        if (B > 1 && ldx < N) { fprintf(stderr, "error in %s: ldx must be >= N\n", fn); return 1; }
+        return stft_host<T>(fn, Y, X, win, B, N, ldx, L, nfft, stp, snip_edges, mn0, amp, lg);
+    }
+    FrameDesc d; size_t W;
+    if (stft_desc(fn, d, B, N, N, L, nfft, stp, snip_edges, mn0, amp, lg, W)) { return 1; }     // the argument checks, before any device work
+    return strided_host<T>(fn, Y, X, win, B, N, ldx, incx, L, B * W * (nfft / 2 + 1), [&](T *yd, const T *xd, const T *wd) {
+        return with_dense_signals<T>(fn, xd, B, N, ldx, incx, nullptr, [&](const T *dense, size_t ld) {
+            return stft_dev<T>(fn, yd, dense, wd, B, N, ld, L, nfft, stp, snip_edges, mn0, amp, lg, nullptr); });
+    });
+}
+
+template <typename T>
+int stft_flt_strided_host(const char *fn, T *Y, const T *X, const T *win, size_t B, size_t N, size_t ldx, size_t incx, size_t L, size_t W, size_t nfft,
+                          T c0, T stp, int mn0, int amp, int lg)
+{
+    if (incx == 1) { return stft_flt_host<T>(fn, Y, X, win, N, L, W, nfft, c0, stp, mn0, amp, lg, B, ldx); }
+    const T stp_min = (T)FLT_EPSILON;
+    if (W > N || L > N || L < 1u || N < 1u || c0 > (T)(N - 1u) || stp < stp_min || nfft < L || nfft < 2u || W == 0) {
+        FrameDesc d; std::shared_ptr<int> hold;                       // (the argument checks and their messages)
+        return flt_desc<T>(fn, 0, d, B, N, N, L, W, nfft, c0, stp, mn0, amp, lg, !tl_flt_intended, true, hold, stp_min);
+    }
+    return strided_host<T>(fn, Y, X, win, B, N, ldx, incx, L, B * W * (nfft / 2 + 1), [&](T *yd, const T *xd, const T *wd) {
+        return with_dense_signals<T>(fn, xd, B, N, ldx, incx, nullptr, [&](const T *dense, size_t ld) {
+            return stft_flt_dev<T>(fn, yd, dense, wd, B, N, ld, L, W, nfft, c0, stp, mn0, amp, lg, nullptr); });
+    });
+}
+
 // ------------------------------------------------------------------------------------------------
 // several GPUs from one process: signals split in contiguous blocks, no reduction
 // ------------------------------------------------------------------------------------------------
@@ -1616,6 +1672,15 @@ int dsp_stft_batch_d(double *Y, const double *X, const double *win, const size_t
     if (B > 1 && ldx < N) { fprintf(stderr, "error in dsp_stft_batch_d: ldx must be >= N\n"); return 1; }
     return stft_host<double>("dsp_stft_batch_d", Y, X, win, B, N, ldx, L, nfft, stp, snip_edges, mn0, amp, lg);
 }
+
+int dsp_stft_batch_strided_s(float *Y, const float *X, const float *win, const size_t B, const size_t N, const size_t ldx, const size_t incx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg)
+{ return stft_strided_host<float>("dsp_stft_batch_strided_s", Y, X, win, B, N, ldx, incx, L, nfft, stp, snip_edges, mn0, amp, lg); }
+int dsp_stft_batch_strided_d(double *Y, const double *X, const double *win, const size_t B, const size_t N, const size_t ldx, const size_t incx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg)
+{ return stft_strided_host<double>("dsp_stft_batch_strided_d", Y, X, win, B, N, ldx, incx, L, nfft, stp, snip_edges, mn0, amp, lg); }
+int dsp_stft_flt_batch_strided_s(float *Y, const float *X, const float *win, const size_t B, const size_t N, const size_t ldx, const size_t incx, const size_t L, const size_t W, const size_t nfft, const float c0, const float stp, const int mn0, const int amp, const int lg)
+{ return stft_flt_strided_host<float>("dsp_stft_flt_batch_strided_s", Y, X, win, B, N, ldx, incx, L, W, nfft, c0, stp, mn0, amp, lg); }
+int dsp_stft_flt_batch_strided_d(double *Y, const double *X, const double *win, const size_t B, const size_t N, const size_t ldx, const size_t incx, const size_t L, const size_t W, const size_t nfft, const double c0, const double stp, const int mn0, const int amp, const int lg)
+{ return stft_flt_strided_host<double>("dsp_stft_flt_batch_strided_d", Y, X, win, B, N, ldx, incx, L, W, nfft, c0, stp, mn0, amp, lg); }
 
 void dsp_shard_range(const size_t B, const size_t rank, const size_t world, size_t *lo, size_t *hi)
 {

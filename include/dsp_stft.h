@@ -261,6 +261,15 @@ int dsp_stft_batch_d (double *Y, const double *X, const double *win, const size_
 int dsp_stft_flt_batch_s (float *Y, const float *X, const float *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t W, const size_t nfft, const float c0, const float stp, const int mn0, const int amp, const int lg);
 int dsp_stft_flt_batch_d (double *Y, const double *X, const double *win, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t W, const size_t nfft, const double c0, const double stp, const int mn0, const int amp, const int lg);
 
+/* Host-pointer forms for signals with a sample stride (sample n of signal b at X[b*ldx + n*incx]): what the tools call
+ * for a multivariate file whose channels are interleaved (row-major [N][C]: B = C, ldx = 1, incx = C; the layout of
+ * c/fft.fftw.r2hc.c:63-65).  The span of X that holds the signals is copied to the device as it lies, the signals are
+ * gathered there, Y[b][W][F] comes back dense.  incx = 1 is dsp_stft_batch_s/_d and dsp_stft_flt_batch_s/_d. */
+int dsp_stft_batch_strided_s (float *Y, const float *X, const float *win, const size_t B, const size_t N, const size_t ldx, const size_t incx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg);
+int dsp_stft_batch_strided_d (double *Y, const double *X, const double *win, const size_t B, const size_t N, const size_t ldx, const size_t incx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg);
+int dsp_stft_flt_batch_strided_s (float *Y, const float *X, const float *win, const size_t B, const size_t N, const size_t ldx, const size_t incx, const size_t L, const size_t W, const size_t nfft, const float c0, const float stp, const int mn0, const int amp, const int lg);
+int dsp_stft_flt_batch_strided_d (double *Y, const double *X, const double *win, const size_t B, const size_t N, const size_t ldx, const size_t incx, const size_t L, const size_t W, const size_t nfft, const double c0, const double stp, const int mn0, const int amp, const int lg);
+
 /* Several GPUs from one process (the reference is one process, src/stft.cpp:219).  The B signals are split in
  * contiguous blocks, GPU g of ngpu taking signals [lo, hi) = dsp_shard_range(B, g, ngpu): blocks of
  * ceil(B / ngpu), the last ones short or empty.  No data crosses between GPUs on the way: every signal is

@@ -114,6 +114,8 @@ def test_option_grammar_and_checks_before_compute(tools, tmp_path):
     np.save(mat, np.zeros((4, 5), np.float32)); np.save(cx, np.zeros(8, np.complex64))
     stft, flt = os.path.join(tools, "stft"), os.path.join(tools, "stft_flt")
     out = str(tmp_path / "y.npy")
+    cube, w5, matF = tmp_path / "cube.npy", tmp_path / "w5.npy", tmp_path / "mF.npy"
+    np.save(cube, np.zeros((2, 3, 4), np.float32)); np.save(w5, np.ones(3, np.float32)); np.save(matF, np.asfortranarray(np.zeros((4, 5), np.float32)))
     cases = [
         ([stft, "-h"], 1, b"", b"Usage: stft"),
         ([stft, "--help"], 1, b"", b"--snip-edges"),
@@ -133,6 +135,15 @@ def test_option_grammar_and_checks_before_compute(tools, tmp_path):
         ([flt, "-s0", str(x32), str(w32), "-o", out], 1, b"stp (step size) must be positive", b""),
         ([flt, "-w0", str(x32), str(w32), "-o", out], 1, b"W (nframes) must be positive", b""),
         ([flt, str(x32), str(mat), "-o", out], 1, b"input 2 (X2) must be a vector", b""),
+        # the opt-in additions: a matrix of signals, devices
+        ([stft, "-d2", str(mat), str(w32), "-o", out], 1, b"dim must be in {0,1}", b""),
+        ([stft, "-d0", str(cube), str(w32), "-o", out], 1, b"input 1 (X1) must be a matrix or a vector with -d", b""),
+        ([stft, "--device", "0", "--ngpu", "2", str(x32), str(w32), "-o", out], 1, b"--device and --ngpu cannot be combined", b""),
+        ([stft, "--ngpu", "0", str(x32), str(w32), "-o", out], 1, b"ngpu must be in [1 64]", b""),
+        ([stft, "--device", "99", str(x32), str(w32), "-o", out], 1, b"device must be in [0 63]", b""),
+        ([stft, "-d0", "--ngpu", "2", str(mat), str(w5), "-o", out], 1, b"with --ngpu the signals must be contiguous", b""),
+        ([flt, "-d", "1", "--ngpu=2", str(matF), str(w5), "-o", out], 1, b"with --ngpu the signals must be contiguous", b""),
+        ([flt, "-d0", "-c", "4", str(mat), str(w5), "-o", out], 1, b"c0 (center of first frame) must be <= N-1", b""),
     ]
     for args, rc, err, outtxt in cases:
         r = run(args)
@@ -264,3 +275,57 @@ def test_stft_flt_tool_matches_oracle(tools, O, tmp_path, dt):
         rc, Yref = O.stft_flt(x, win, W, c0, stp, 512, 0, 0, 0, intended=intended)
         assert rc == 0
         check(O, np.load(yp), Yref)
+
+
+@gpu
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_tools_on_a_matrix_of_signals(tools, O, tmp_path, dt):
+    """-d: every vector along one axis of a matrix is a signal.  All four layouts (axis x major order): interleaved channels
+    go through the strided entry points, contiguous ones through the batched ones; the output is one W x F block per
+    signal, B x W x F for a row-major file and F x W x B for a column-major one (the same bytes).  Each block against the
+    oracle's result for that channel alone and, bit for bit, against the tool run on the channel as a vector."""
+    rng = np.random.default_rng(11)
+    C_, N = 5, 6000
+    sig = (rng.standard_normal((C_, N)) * 0.1).astype(dt)            # [channel][sample]
+    import dsp_amd
+    win = dsp_amd.hamming(400, dt)
+    wp = tmp_path / "w.npy"
+    np.save(wp, win)
+    stft, flt = os.path.join(tools, "stft"), os.path.join(tools, "stft_flt")
+    layouts = {
+        "rows_are_signals_rowmajor": (np.ascontiguousarray(sig), "1"),                # [C][N], contiguous signals
+        "cols_are_signals_rowmajor": (np.ascontiguousarray(sig.T), "0"),              # [N][C], interleaved
+        "cols_are_signals_colmajor": (np.asfortranarray(sig.T), "0"),                 # N x C column-major: contiguous
+        "rows_are_signals_colmajor": (np.asfortranarray(sig), "1"),                   # C x N column-major: interleaved
+    }
+    ref = [O.stft(sig[c], win, 160, 512, 0, 1)[1] for c in range(C_)]
+    W = int((N - 1 - 200) // 160.5)
+    ref_flt = [O.stft_flt(sig[c], win, W, 200.0, 160.5)[1] for c in range(C_)]
+    alone = []
+    for c in range(C_):
+        xp, yp = tmp_path / "x1.npy", tmp_path / "y1.npy"
+        np.save(xp, sig[c])
+        r = run([stft, "-z", str(xp), str(wp), "-o", str(yp)])
+        assert r.returncode == 0, r.stderr
+        alone.append(np.load(yp))
+    for name, (arr, d) in layouts.items():
+        xp, yp = tmp_path / (name + ".npy"), tmp_path / (name + "_y.npy")
+        np.save(xp, arr)
+        r = run([stft, "-z", "-d", d, "--device", "0", str(xp), str(wp), "-o", str(yp)])
+        assert r.returncode == 0, (name, r.stderr)
+        Y = np.load(yp)
+        col = arr.flags["F_CONTIGUOUS"] and not arr.flags["C_CONTIGUOUS"]
+        assert Y.shape == ((257, ref[0].shape[0], C_) if col else (C_, ref[0].shape[0], 257)), (name, Y.shape)
+        Yb = Y.transpose(2, 1, 0) if col else Y                    # [b][w][f]
+        for c in range(C_):
+            check(O, np.ascontiguousarray(Yb[c]), ref[c])
+            assert np.array_equal(Yb[c], alone[c]), (name, c)
+        r = run([flt, "-d" + d, "-c200", "-s160.5", "-w", str(W), "--ngpu", "1", str(xp), str(wp), "-o", str(yp)])
+        assert r.returncode == 0, (name, r.stderr)
+        Y = np.load(yp)
+        Yb = Y.transpose(2, 1, 0) if col else Y
+        for c in range(C_):
+            check(O, np.ascontiguousarray(Yb[c]), ref_flt[c])
+    # a device the box does not have: the library's own error line, exit code 1
+    r = run([stft, "--device", "63", str(tmp_path / "x1.npy"), str(wp), "-o", str(tmp_path / "z.npy")])
+    assert r.returncode == 1 and b"error" in r.stderr

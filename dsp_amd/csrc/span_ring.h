@@ -20,7 +20,17 @@ __device__ __forceinline__ unsigned ring_lds_addr(const void *p)
 {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
 }
-template <int N> __device__ __forceinline__ void ring_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// The counted wait: until at most N memory operations of the wave are outstanding.  Memory operations complete in
+// issue order, so with exactly N store instructions issued behind a span's loads this waits for the span and leaves
+// the stores in flight.  The count is an assumption about the code the compiler emits between the two points; it is
+// checked on the built library (tests/test_asm_waits.py), and DSP_SAFE_WAITS = 1 builds every such wait as a wait for
+// all outstanding operations (libdsp_stft_hip_safe.so, compared bit for bit with the counted build on the GPU).
+#ifndef DSP_SAFE_WAITS
+#define DSP_SAFE_WAITS 0
+#endif
+// (expcnt(6) marks the instruction for that check: these kernels issue nothing that the export counter counts, so the
+// field never waits, and the compiler's own waits never carry it)
+template <int N> __device__ __forceinline__ void ring_wait_vm() { asm volatile("s_waitcnt vmcnt(%0) expcnt(6)" ::"n"(DSP_SAFE_WAITS ? 0 : N) : "memory"); }
 // Draw of a step: lane 0 alone adds 1 to the workgroup's counter (LDS byte address `cnt`); the old value is in
 // lane 0 of `t` once ring_drawn has waited for it.  In assembly for the same reason as the load above: the
 // compiler's form waits for the answer on the spot.

@@ -1006,6 +1006,55 @@ def test_bench_two_rank_rehearsal_in_a_fresh_process():
     assert isinstance(d.get("gather"), dict) and "error" not in d["gather"], d.get("gather")
 
 
+def test_counted_waits_against_full_waits():
+    """The span-staging kernels wait for their LDS-DMA loads with counted waits that leave the row stores in flight.
+    libdsp_stft_hip_safe.so is the same code with every such wait built as a wait for everything outstanding
+    (-DDSP_SAFE_WAITS=1): both builds must return the same bits -- on the benchmark's batch (every signal's exact checksum,
+    three launches each) and on the shapes of the 256-, 1024- and 2048-point kernels.  The safe build runs in a child
+    process (one library per process)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    safe = os.path.join(root, "dsp_amd", "libdsp_stft_hip_safe.so")
+    assert os.path.exists(safe), "make -C dsp_amd/csrc builds it"
+    prog = r"""
+import json, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, dsp_amd
+out = {}
+def checksum(t):
+    return t.view(torch.int32).to(torch.int64).sum(dim=(1, 2)).cpu().tolist()
+for name, B, N, L, hop, nfft in (("utt", 1024, 160000, 400, 160, 512), ("tel", 256, 80000, 200, 80, 256), ("m1024", 16, 1323000, 1024, 256, 1024),
+                                 ("m2048", 16, 1323000, 2048, 512, 2048), ("odd", 64, 160003, 400, 161, 512)):
+    g = torch.Generator(device="cuda").manual_seed(99)
+    x = torch.randn((B, N), generator=g, device="cuda", dtype=torch.float32) * 0.1
+    win = torch.from_numpy(dsp_amd.hann(L)).cuda()
+    sums = []
+    for rep in range(3):
+        y = dsp_amd.stft_dev(x, win, hop, nfft=nfft)
+        torch.cuda.synchronize()
+        sums.append(checksum(y))
+    assert sums[0] == sums[1] == sums[2]
+    out[name] = sums[0]
+print("RESULT " + json.dumps(out))
+""" % root
+    def run(lib):
+        env = dict(os.environ)
+        if lib:
+            env["DSP_AMD_LIB"] = lib
+        else:
+            env.pop("DSP_AMD_LIB", None)
+        r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=280, env=env, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1]
+        return json.loads(line[7:])
+    counted, full = run(None), run(safe)
+    assert counted.keys() == full.keys()
+    for k in counted:
+        assert counted[k] == full[k], k
+
+
 def test_full_size_chunks_equal_channels_alone(O, D, monkeypatch):
     """The multi-channel launches of the long-signal configurations: 64 and 8 channels of 1 h @ 16 kHz float64
     through stft_flt (Povey 400, hop 160.0, c0 200), 8 channels of 1 h @ 48 kHz float32 with nfft 4096 / hop 1024.

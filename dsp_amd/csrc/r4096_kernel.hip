@@ -86,16 +86,19 @@ typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));   // 16-
 #define R4096_RUN 32            // frames per run of the run form
 #endif
 #ifndef R4096_NT_LOAD
-#define R4096_NT_LOAD 0         // 1: the run form's sample loads carry the non-temporal hint (every sample is read once)
+#define R4096_NT_LOAD 1         // 1: the run form's sample loads carry the non-temporal hint (every sample is read once; measured: 0.8 %)
 #endif
 #ifndef R4096_NT_STORE
 #define R4096_NT_STORE 0        // 1: rows are stored with the non-temporal hint
+#endif
+#ifndef R4096_TA_REG
+#define R4096_TA_REG 0          // 1: run form keeps the twiddle stage's per-lane factors in registers instead of LDS
 #endif
 #ifndef R4096_LOADPOS
 #define R4096_LOADPOS 0         // run form: where the next group's loads are issued: 0 = right after the window step, 1 = after the first transform, 2 = after the exchange
 #endif
 #ifndef R4096_TA_AHEAD
-#define R4096_TA_AHEAD 1        // 1: run form reads the twiddle stage's per-lane factors right after the window step
+#define R4096_TA_AHEAD 0        // 1: run form reads the twiddle stage's per-lane factors right after the window step (measured: 1.7 % slower than reading them where they are used, which frees 14 registers)
 #endif
 #ifndef R4096_HACK
 #define R4096_HACK 0          // timing experiments only (wrong results): bit 1 = twiddle stage without the second factor, bit 3 = rows at a pitch of 2048 values (every store instruction on a 256-byte boundary)
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
 #pragma unroll
             for (int bb = 1; bb < 4; ++bb) { *zp[bb] = cx_mul_second<float>(*zp[bb], tb[bb], t[bb]); }
             if (q && !(R4096_HACK & 2)) {
-                const C2 taq = RUN ? (R4096_TA_AHEAD ? taq_r[q] : twl[64 * q + lane]) : ta[q];
+                const C2 taq = (RUN && !R4096_TA_REG) ? (R4096_TA_AHEAD ? taq_r[q] : twl[64 * q + lane]) : ta[q];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int bb = 0; bb < 4; ++bb) { t[bb] = cx_mul_first<float>(*zp[bb], taq); }

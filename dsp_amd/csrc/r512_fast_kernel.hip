@@ -41,6 +41,8 @@ struct R512FastArgs {
     int all16;            // every step has 4 frames and its block of rows is 16-byte aligned
     int Wy;               // frames per signal in the output array
     double cscale;        // complex form: factor on every output value (1, or 1 / sqrt(2 nfft))
+    int gap;              // hops above 512: samples between the end of a frame and the start of the next (hop - 512) that are
+                          // never read; the frames of a step then lie 512 apart in the staged span (0 otherwise)
 };
 
 constexpr int R512F_WAVE_ELEMS = 4 * R512_EXF * 2;   // T elements of a wave's exchange tile (>= 2048: the longest span)
@@ -208,10 +210,11 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
     if (tid == 0) { *ticket = NWV; }                         // the first 8 steps go to the waves in order
     __syncthreads();
     static_assert(!TBL || WIDE >= 1, "the table form uses the wide instantiations");
-    const int reach = TBL ? a.stp : 3 * a.stp;               // start of the step's last frame relative to its first
+    const int lstp = a.stp - ((WIDE == 2 && !TBL) ? a.gap : 0);   // distance of a step's frames in the staged span
+    const int reach = TBL ? a.stp : 3 * lstp;                // start of the step's last frame relative to its first
     const int need = reach + 512;
     const int nvec = (reach + 32 * NR + VEC - 1) / VEC;      // 16-byte vectors of a span that pass 1 reads
-    const T *xrow = (RING ? slot : xs) + f * a.stp + 2 * j;  // (table form: set per step)
+    const T *xrow = (RING ? slot : xs) + f * lstp + 2 * j;   // (table form: set per step)
     // table form: lane i holds the start of frame w + (i & 3) of a step (clamped to the last frame)
     auto tbl_fetch = [&](const int w_) { return a.tbl[2 * min(w_ + (lane & 3), a.W - 1)]; };
     auto tbl_xrow = [&](const int tv) { return xs + (__shfl(tv, f) - __builtin_amdgcn_readfirstlane(tv)) + 2 * j; };
@@ -231,6 +234,8 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
     // ---- fetch of one span (frames w..w+3 of the signal at xb): into registers, or (RING) into the slot.
     // A span that crosses an edge of its signal (reflection or zeros) is gathered sample by sample.
     TV pre[RING ? 1 : NV];
+    // sample offset (from the start of the span) of staged element e: with a gap, frame e / 512 lies that many gaps further on
+    auto span_off = [&](const int e) { return (WIDE == 2 && !TBL) ? e + (e >> 9) * a.gap : e; };
     auto gather = [&](const T *xb, const int s0, const int q, TV &out) {
         FrameDesc d{};
         d.N = a.N; d.edge = a.edge;
@@ -238,14 +243,14 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
             const int i = (q * 64 + lane) * VEC + v;
-            t[v] = (i < need) ? fetch_sample(xb, d, (long long)s0, (long long)a.rd_shift, i) : T(0);
+            t[v] = (i < need) ? fetch_sample(xb, d, (long long)s0, (long long)a.rd_shift, span_off(i)) : T(0);
         }
         if constexpr (VEC == 4) { out = TV{t[0], t[1], t[2], t[3]}; }
         else { out = TV{t[0], t[1]}; }
     };
     auto load_span = [&](const T *xb, const int s0) {
         const T *src = xb + (s0 - (a.edge ? a.rd_shift : 0));
-        const bool inside = s0 >= 0 && s0 + SPAN <= a.N && (a.edge == 0 || s0 >= a.rd_shift);
+        const bool inside = s0 >= 0 && s0 + SPAN + ((WIDE == 2 && !TBL) ? 3 * a.gap : 0) <= a.N && (a.edge == 0 || s0 >= a.rd_shift);
         if constexpr (RING) {
             // NV LDS-DMA loads per span whatever the case (the counted wait relies on that): behind a gathered
             // span NV placeholder loads follow, from the twiddle table into `dummy`
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
 #if R512F_NOLOAD
                     ring_glds16(tw + lane * VEC, __builtin_amdgcn_readfirstlane(ring_lds_addr(dummy)));
 #else
-                    ring_glds16(src + min(q * 64 + lane, nvec - 1) * VEC, __builtin_amdgcn_readfirstlane(ring_lds_addr(slot + q * 64 * VEC)));
+                    ring_glds16(src + span_off(min(q * 64 + lane, nvec - 1) * VEC), __builtin_amdgcn_readfirstlane(ring_lds_addr(slot + q * 64 * VEC)));
 #endif
                 }
             } else {
@@ -269,14 +274,14 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
 #pragma unroll
                 for (int q = 0; q < NV; ++q) { ring_glds16(tw + lane * VEC, __builtin_amdgcn_readfirstlane(ring_lds_addr(dummy))); }
             }
-        } else if (inside && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+        } else if (inside && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && (!(WIDE == 2 && !TBL) || (a.gap * (int)sizeof(T)) % 16 == 0)) {
 #pragma unroll
             for (int q = 0; q < NV; ++q) {
                 // lanes past the last needed vector re-read it (same cache line, no extra traffic): the number of loads stays fixed
 #if R512F_NOLOAD
                 if (a.N == -12345)
 #endif
-                pre[RING ? 0 : q] = reinterpret_cast<const TV *>(src)[min(q * 64 + lane, nvec - 1)];
+                pre[RING ? 0 : q] = *reinterpret_cast<const TV *>(src + span_off(min(q * 64 + lane, nvec - 1) * VEC));
             }
         } else if (inside) {
             // a span that does not start on a 16-byte boundary (odd ss0, a hop that is no multiple of 4
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
             using TVu = typename vec16u<T>::type;
 #pragma unroll
             for (int q = 0; q < NV; ++q) {
-                const TVu v = reinterpret_cast<const TVu *>(src)[min(q * 64 + lane, nvec - 1)];
+                const TVu v = *reinterpret_cast<const TVu *>(src + span_off(min(q * 64 + lane, nvec - 1) * VEC));
                 if constexpr (VEC == 4) { pre[RING ? 0 : q] = TV{v.x, v.y, v.z, v.w}; }
                 else { pre[RING ? 0 : q] = TV{v.x, v.y}; }
             }
@@ -636,7 +641,8 @@ extern "C" int dsp_debug_read_stamps(unsigned long long *dst, size_t n)
 // and every index of one signal's input and output fits 31 bits.
 bool r512_fast_supported(const FrameDesc &d)
 {
-    const bool placed = d.tbl ? (d.tbl_reach >= 0 && d.tbl_reach + 512 <= 2048) : (3ll * d.stp + 512 <= 2048);
+    // equally spaced frames at any hop: above 512 the samples between two frames are skipped when a span is fetched
+    const bool placed = d.tbl ? (d.tbl_reach >= 0 && d.tbl_reach + 512 <= 2048) : (d.stp >= 1 && d.stp < (1 << 28));
     return placed && d.nfft == 512 && d.L >= 1 && d.L <= 512 &&
            d.N < (1ll << 31) - 4096 && (long long)d.wy() * 257 < (1ll << 30) && (long long)d.B * ((d.W + 3) / 4) < (1ll << 30) && d.ss0 > -(1ll << 30) && d.ss0 < (1ll << 30) &&
            d.rd_shift >= 0 && d.rd_shift < (1ll << 30);
@@ -694,6 +700,7 @@ static hipError_t launch_stft_r512_fast_one(T *Y, const T *X, const T *win, cons
     a.sps = (d.W + 3) / 4;
     a.steps = d.B * a.sps;
     a.tbl = d.tbl;
+    a.gap = (!d.tbl && d.stp > 512) ? d.stp - 512 : 0;
     if (d.tbl) { a.stp = d.tbl_reach; a.ss0 = 0; a.rd_shift = 0; }
     a.all16 = (d.W % 4 == 0) && (d.wy() % 4 == 0) && (reinterpret_cast<uintptr_t>(Y) % 16 == 0);
     a.Wy = d.wy();
@@ -770,6 +777,7 @@ hipError_t launch_stft_r512_fast_cplx(T *Y, const T *X, const T *win, const T *t
     a.sps = (d.W + 3) / 4;
     a.steps = d.B * a.sps;
     a.tbl = nullptr;
+    a.gap = d.stp > 512 ? d.stp - 512 : 0;
     a.cscale = scale;
     a.all16 = (d.W % 4 == 0) && (d.wy() % 4 == 0) && (reinterpret_cast<uintptr_t>(Y) % 16 == 0);
     a.Wy = d.wy();

@@ -1055,6 +1055,30 @@ print("RESULT " + json.dumps(out))
         assert counted[k] == full[k], k
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_hops_above_512_on_the_span_kernel(O, D, dt):
+    """nfft 512 with frames further apart than a transform length (hop > 512): the span-staging kernel fetches the four
+    frames of a step as four pieces and skips what lies between them.  Signals long enough for interior steps, both
+    edge rules (stft reflects, stft_flt pads with zeros), odd hops and short windows; every signal against the oracle."""
+    import torch
+    rng = np.random.default_rng(512)
+    for L, hop, N in ((512, 600, 40000), (512, 513, 30011), (400, 801, 50000), (512, 1024, 66000), (33, 2000, 70001)):
+        x = (rng.standard_normal((3, N)) * 0.1).astype(dt)
+        win = D.hamming(L, dt)
+        for snip in (False, True):
+            Y = D.stft_dev(torch.from_numpy(x).cuda(), torch.from_numpy(win).cuda(), hop, nfft=512, snip_edges=snip).cpu().numpy()
+            for b in range(3):
+                rc, Yref = O.stft(x[b], win, hop, 512, int(snip))
+                assert rc == 0
+                check_spec(O, Y[b], Yref)
+        W = (N - 1) // hop
+        Z = D.stft_flt_dev(torch.from_numpy(x).cuda(), torch.from_numpy(win).cuda(), W, float(L // 2), float(hop), nfft=512, mn0=True).cpu().numpy()
+        for b in range(3):
+            rc, Zref = O.stft_flt(x[b], win, W, float(L // 2), float(hop), 512, 1)
+            assert rc == 0
+            check_spec(O, Z[b], Zref)
+
+
 def test_full_size_chunks_equal_channels_alone(O, D, monkeypatch):
     """The multi-channel launches of the long-signal configurations: 64 and 8 channels of 1 h @ 16 kHz float64
     through stft_flt (Povey 400, hop 160.0, c0 200), 8 channels of 1 h @ 48 kHz float32 with nfft 4096 / hop 1024.

@@ -306,7 +306,7 @@ int family_of(size_t nfft)
     if (nfft < 2) { return 0; }
     if (!is_pow2(nfft)) { return 1; }
     if (nfft == 512 && !tl_force_generic) { return 3; }
-    if (nfft == 4096 && sizeof(T) == 4 && !tl_force_generic) { return 4; }
+    if (nfft == 4096 && !tl_force_generic) { return 4; }
     if ((nfft == 1024 || nfft == 2048) && !tl_force_generic) { return 6; }
     if ((nfft == 256 || nfft == 128 || nfft == 64) && !tl_force_generic) { return 7; }
     if (!tl_force_generic && nfft <= (1u << 20)) {
@@ -351,11 +351,9 @@ int run_fused(const char *fn, int dev, T *Yd, const T *Xd, const T *wd, const Fr
         HIPCHK(fn, launch_stft_r512<T>(Yd, Xd, wd, tw, d, s));
         return 0;
     }
-    if constexpr (sizeof(T) == 4) {
-        if (fam == 4 && r4096_supported(d)) {
-            HIPCHK(fn, launch_stft_r4096(Yd, Xd, wd, tw, d, s, take));
-            return 0;
-        }
+    if (fam == 4 && r4096_supported(d)) {
+        HIPCHK(fn, launch_stft_r4096(Yd, Xd, wd, tw, d, s, take));
+        return 0;
     }
     if (fam == 6 && r512x_supported(d)) {
         HIPCHK(fn, launch_stft_r512x(Yd, Xd, wd, tw, d, s));
@@ -1363,12 +1361,10 @@ int stft_cplx_dev(const char *fn, T *Yd, const T *Xd, const T *wd, size_t B, siz
         HIPCHK(fn, launch_stft_r256_cplx(Yd, Xd, wd, tw, d, scale, s));
         return 0;
     }
-    if constexpr (sizeof(T) == 4) {
-        if (nfft == 4096 && !tl_force_generic && r4096_cplx_supported(d)) {
-            if (get_twiddles<T>(fn, dev, nfft, 0, tw)) { return 1; }
-            HIPCHK(fn, launch_stft_r4096_cplx(Yd, Xd, wd, tw, d, scale, s));
-            return 0;
-        }
+    if (nfft == 4096 && !tl_force_generic && r4096_cplx_supported(d)) {
+        if (get_twiddles<T>(fn, dev, nfft, 0, tw)) { return 1; }
+        HIPCHK(fn, launch_stft_r4096_cplx(Yd, Xd, wd, tw, d, scale, s));
+        return 0;
     }
     if ((pow2 ? nfft : L) * sizeof(T) > LDS_LIMIT) { fprintf(stderr, "error in %s: nfft too large (limit %zu)\n", fn, LDS_LIMIT / sizeof(T)); return 1; }
     if (get_twiddles<T>(fn, dev, nfft, pow2 ? 0 : 1, tw)) { return 1; }

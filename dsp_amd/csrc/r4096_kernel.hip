@@ -45,7 +45,7 @@ struct R4096Args {
     int frames;           // B * W
     int B;                // signals
     unsigned *take;       // run form: 8 counters (one per blockIdx % 8), zero at launch
-    float cscale;         // complex form: factor on every output value
+    double cscale;        // complex form: factor on every output value
 };
 
 // Counters of the run form: R4096_SLOTS sets of 8, used in turn by successive launches on a device (how a
@@ -58,10 +58,15 @@ constexpr int R4096_WAVE_C = 64 * R4096_PITCH;          // complex slots per wav
 #ifndef R4096_NWAVES
 #define R4096_NWAVES 8
 #endif
-constexpr int R4096_WAVES = R4096_NWAVES;               // waves per workgroup (share the window table)
-typedef float float2_u __attribute__((ext_vector_type(2), aligned(4)));   // 8-byte access at 4-byte alignment (frame starts are only 4-byte aligned)
+// waves per workgroup (they share the window table): float64 takes twice the LDS and twice the registers per wave
+template <typename T> constexpr int r4096_waves() { return sizeof(T) == 4 ? R4096_NWAVES : R4096_NWAVES / 2; }
+// a pair of samples accessed at the alignment of one (frame starts are only aligned to a sample)
+typedef float float2_u __attribute__((ext_vector_type(2), aligned(4)));
+typedef double double2_u __attribute__((ext_vector_type(2), aligned(8)));
+template <typename T> struct pair_u_of;
+template <> struct pair_u_of<float> { using type = float2_u; };
+template <> struct pair_u_of<double> { using type = double2_u; };
 typedef unsigned u2v __attribute__((ext_vector_type(2)));
-typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access at 4-byte alignment
 
 #ifndef R4096_ABLATE
 #define R4096_ABLATE 0          // diagnostic builds: bit 0 = no row stores, bit 1 = no sample loads
@@ -100,6 +105,9 @@ typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));   // 16-
 #ifndef R4096_TA_AHEAD
 #define R4096_TA_AHEAD 0        // 1: run form reads the twiddle stage's per-lane factors right after the window step (measured: 1.7 % slower than reading them where they are used, which frees 14 registers)
 #endif
+#ifndef R4096_WREG_F64
+#define R4096_WREG_F64 1        // 1: the plain run form keeps the window in registers in float64 as well (128 of the wave's 512)
+#endif
 #ifndef R4096_HACK
 #define R4096_HACK 0          // timing experiments only (wrong results): bit 1 = twiddle stage without the second factor, bit 3 = rows at a pitch of 2048 values (every store instruction on a 256-byte boundary)
 #endif
@@ -120,15 +128,32 @@ __device__ unsigned long long g_r4096_stamps[2048 * 10];   // per wave: 8 phase 
 #define R4096_STAMP(i) do {} while (0)
 #endif
 
-using C2 = cx<float>;
 
 constexpr int R4096_X2P = 17;                           // second exchange: complex slots per lane (16 values + 1)
 // which instantiations keep the window in registers instead of LDS: the run form without mean removal, epilogue or
 // complex rows (those need the registers themselves)
 constexpr bool r4096_wreg(bool mn0, bool epi, bool run, bool cplx) { return run && !mn0 && !epi && !cplx; }
+constexpr size_t r4096_lds(size_t elem, int waves, bool wtab, bool run) { return 2 * elem * ((size_t)waves * R4096_WAVE_C + (run ? 64 * 8 : 0)) + (wtab ? 4096 * elem : 0); }
 
 // |a|^2 as a plain multiply and a plain fma: 2 + 2 issue cycles, where the packed square and the add of its halves take 4 + 2
-__device__ __forceinline__ float norm2(const C2 a) { return fmaf(a.y, a.y, a.x * a.x); }
+__device__ __forceinline__ float norm2(const cxf a) { return fmaf(a.y, a.y, a.x * a.x); }
+__device__ __forceinline__ double norm2(const cxd a) { return fma(a.y, a.y, a.x * a.x); }
+// x = (lower half-wave: lo of its own lane | upper: lo of the lane 32 below), y = (lower: hi of the lane 32 above | upper: its own hi):
+// v_permlane32_swap on every 32-bit half of the value
+__device__ __forceinline__ void half_swap(const float lo, const float hi, float &x, float &y)
+{
+    const u2v s = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+    x = __uint_as_float(s.x); y = __uint_as_float(s.y);
+}
+__device__ __forceinline__ void half_swap(const double lo, const double hi, double &x, double &y)
+{
+    const u2v a = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(lo), (unsigned)__double2loint(hi), false, false);
+    const u2v b = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(lo), (unsigned)__double2hiint(hi), false, false);
+    x = __hiloint2double((int)b.x, (int)a.x); y = __hiloint2double((int)b.y, (int)a.y);
+}
+// keeps a value in its registers across this point (no rematerialisation, nothing moved across)
+__device__ __forceinline__ void pin(cxf &a) { asm volatile("" : "+v"(a)); }
+__device__ __forceinline__ void pin(cxd &a) { asm volatile("" : "+v"(a.x), "+v"(a.y)); }
 
 template <int R> using rot = std::integral_constant<int, R>;
 
@@ -137,11 +162,14 @@ template <int R> using rot = std::integral_constant<int, R>;
 // their powers.  In the run form the frame in the registers is the true one rotated by ROT quarters of its length, which
 // multiplies bin k by (-i)^(ROT k): the complex form multiplies back by i^(ROT k) -- a swap and a sign, chosen at compile
 // time, since a lane's bins are 4 lane + c + 256 m and 2048 minus those.
-template <bool FULL, bool MN0, bool EPI, bool RUN, bool CPLX = false>
-__global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *__restrict__ Y, const float *__restrict__ X,
-                                                                         const float *__restrict__ win, const float *__restrict__ tw,
-                                                                         const R4096Args a)
+template <typename T, bool FULL, bool MN0, bool EPI, bool RUN, bool CPLX = false>
+__global__ __launch_bounds__(64 * r4096_waves<T>(), r4096_waves<T>() / 4) void stft_r4096_kernel(T *__restrict__ Y, const T *__restrict__ X,
+                                                                                                   const T *__restrict__ win, const T *__restrict__ tw,
+                                                                                                   const R4096Args a)
 {
+    using C2 = cx<T>;
+    using pair_u = typename pair_u_of<T>::type;
+    constexpr int R4096_WAVES = r4096_waves<T>();
     constexpr int M = 2048, F = 2049;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -149,13 +177,16 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
     const int L = a.L;
     // The halved window, 4096 floats, in front of the tiles -- except in the plain run form (WREG), which has the
     // registers to keep a lane's 64 window values for the whole launch.
-    constexpr bool WREG = r4096_wreg(MN0, EPI, RUN, CPLX);
-    float *wtab = reinterpret_cast<float *>(smem_raw);
-    C2 *tiles = reinterpret_cast<C2 *>(smem_raw) + (WREG ? 0 : 2048);
+    // float64 has no LDS left for the table (4 tiles of 33.8 KB): its other instantiations read the window from memory
+    // (32 KB that the L2 keeps) frame by frame.
+    constexpr bool WREG = r4096_wreg(MN0, EPI, RUN, CPLX) && (sizeof(T) == 4 || R4096_WREG_F64);
+    constexpr bool WTAB = !WREG && sizeof(T) == 4;
+    T *wtab = reinterpret_cast<T *>(smem_raw);
+    C2 *tiles = reinterpret_cast<C2 *>(smem_raw) + (WTAB ? 2048 : 0);
     C2 *ex = tiles + wv * R4096_WAVE_C;                                               // this wave's tile
 
-    if constexpr (!WREG) {
-        for (int l = tid; l < 4096; l += 64 * R4096_WAVES) { wtab[l] = (l < L) ? 0.5f * win[l] : 0.0f; }
+    if constexpr (WTAB) {
+        for (int l = tid; l < 4096; l += 64 * R4096_WAVES) { wtab[l] = (l < L) ? T(0.5) * win[l] : T(0); }
     }
 
     // Lane roles.  Pass 1: the lane is the complex column n2 = lane and holds its 32 rows n1 (z[n2 + 64 n1] = samples
@@ -165,8 +196,8 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
     // per-lane twiddles: W2048^(n2 b), b = 1..3, and W2048^(4 n2 a), a = 1..7
     auto tw2048 = [&](int m) {                            // W2048^m = W4096^(2m), table holds k < 2048
         int idx = (2 * m) & 4095;
-        float sg = 1.0f;
-        if (idx >= 2048) { idx -= 2048; sg = -1.0f; }
+        T sg = T(1);
+        if (idx >= 2048) { idx -= 2048; sg = T(-1); }
         return C2{sg * tw[2 * idx], sg * tw[2 * idx + 1]};
     };
     C2 tb[4], ta[8];
@@ -215,7 +246,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
     if (fid >= f_hi) { return; }
 
     // where frame f lies: output row, first sample, and whether all 4096 samples can be read in place
-    struct Where { long long row; const float *xb; long long ss, rdoff; bool inside; };
+    struct Where { long long row; const T *xb; long long ss, rdoff; bool inside; };
     auto locate = [&](int f) {
         Where q;
         const int b = f / a.W;
@@ -235,14 +266,14 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
     const int loff = 2 * lane;                              // first sample of the lane inside a frame; row i adds 128
     // raw samples of a frame that lies inside its signal: 32 coalesced 512-byte wave loads
     auto load_inside = [&](const Where &q) {
-        const float *src = q.xb + (q.ss - q.rdoff) + loff;
+        const T *src = q.xb + (q.ss - q.rdoff) + loff;
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
-            float2_u v = {0.f, 0.f};
+            pair_u v = {T(0), T(0)};
 #if R4096_ABLATE & 2
             if (a.N == -12345)
 #endif
-            if (FULL || 128 * i < L) { v = *reinterpret_cast<const float2_u *>(src + 128 * i); }
+            if (FULL || 128 * i < L) { v = *reinterpret_cast<const pair_u *>(src + 128 * i); }
             pre[i] = C2{v.x, v.y};
         }
     };
@@ -250,9 +281,9 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
     auto load_edge = [&](const Where &q) {
         FrameDesc d{};
         d.N = a.N; d.edge = a.edge;
-        float *stage = reinterpret_cast<float *>(ex);
+        T *stage = reinterpret_cast<T *>(ex);
         wave_sync();
-        for (int l = lane; l < 4096; l += 64) { stage[l] = (l < L) ? fetch_sample(q.xb, d, q.ss, q.rdoff, l) : 0.f; }
+        for (int l = lane; l < 4096; l += 64) { stage[l] = (l < L) ? fetch_sample(q.xb, d, q.ss, q.rdoff, l) : T(0); }
         wave_sync();
 #pragma unroll
         for (int i = 0; i < 32; ++i) { pre[i] = *reinterpret_cast<const C2 *>(stage + loff + 128 * i); }
@@ -268,9 +299,9 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
     };
     // Group g of the run (b, w0): where its 1024 samples lie.  A group that crosses an edge of the
     // signal is gathered sample by sample into the tile first, which is idle at the call sites.
-    struct Group { const float *src; bool inside; };
+    struct Group { const T *src; bool inside; };
     auto find_group = [&](int b, int w0, int g) {
-        const float *xb = X + (long long)b * a.ldx;
+        const T *xb = X + (long long)b * a.ldx;
         const long long ssg = a.ss0 + (long long)w0 * a.stp + 1024LL * g;
         const long long rdoff = a.edge ? a.rd_shift : 0;
         Group q;
@@ -279,7 +310,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         if (!q.inside) {
             FrameDesc d{};
             d.N = a.N; d.edge = a.edge;
-            float *stage = reinterpret_cast<float *>(ex);
+            T *stage = reinterpret_cast<T *>(ex);
             wave_sync();
             for (int l = lane; l < 1024; l += 64) { stage[l] = fetch_sample(xb, d, ssg, rdoff, l); }
             wave_sync();
@@ -292,14 +323,14 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
 #if R4096_NT_LOAD
-                const float2_u v = __builtin_nontemporal_load(reinterpret_cast<const float2_u *>(q.src + 128 * r));
+                const pair_u v = __builtin_nontemporal_load(reinterpret_cast<const pair_u *>(q.src + 128 * r));
 #else
-                const float2_u v = *reinterpret_cast<const float2_u *>(q.src + 128 * r);
+                const pair_u v = *reinterpret_cast<const pair_u *>(q.src + 128 * r);
 #endif
                 pre[8 * j + r] = C2{v.x, v.y};
             }
         } else {
-            const float *stage = reinterpret_cast<const float *>(ex);
+            const T *stage = reinterpret_cast<const T *>(ex);
 #pragma unroll
             for (int r = 0; r < 8; ++r) { pre[8 * j + r] = *reinterpret_cast<const C2 *>(stage + loff + 128 * r); }
             asm volatile("" ::: "memory");
@@ -318,8 +349,8 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
     if constexpr (WREG) {
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
-            const float2 w2 = *reinterpret_cast<const float2 *>(win + loff + 128 * i);
-            wreg[i] = C2{0.5f * w2.x, 0.5f * w2.y};
+            const pair_u w2 = *reinterpret_cast<const pair_u *>(win + loff + 128 * i);
+            wreg[i] = C2{T(0.5) * w2.x, T(0.5) * w2.y};
         }
     }
     Where cur{};
@@ -337,9 +368,9 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
     // forward 32-point DFT of x[n], n < 32, given as even part e[m] = x[2m] and odd part o[m] = x[2m+1]; on return X[k]
     // is in e[slot16(k)] for k < 16 and in o[slot16(k - 16)] for k >= 16.  Twiddles folded into the additions (fft16.h).
     auto dft32f = [](C2 (&e)[16], C2 (&o)[16]) __attribute__((always_inline)) {
-        dft16f<float, 16>(e);
-        dft16f<float, 16>(o);
-#define R4096_B(K) bfly_tw<float, 32, K>(e[slot16(K)], o[slot16(K)]);
+        dft16f<T, 16>(e);
+        dft16f<T, 16>(o);
+#define R4096_B(K) bfly_tw<T, 32, K>(e[slot16(K)], o[slot16(K)]);
         R4096_B(0) R4096_B(1) R4096_B(2) R4096_B(3) R4096_B(4) R4096_B(5) R4096_B(6) R4096_B(7)
         R4096_B(8) R4096_B(9) R4096_B(10) R4096_B(11) R4096_B(12) R4096_B(13) R4096_B(14) R4096_B(15)
 #undef R4096_B
@@ -363,7 +394,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         // ---------------- pass 1: window, 32-point FFT over n1 ----------------
         R4096_PRIO(4, 1);
         {
-            C2 acc = C2{0.f, 0.f};
+            C2 acc = C2{T(0), T(0)};
             int lim = L - loff;                              // sample l = 128 i + loff + c is inside the window iff 128 i + c < lim
             asm volatile("" : "+v"(lim));                    // recomputed per frame: hoisted lane masks would not fit in SGPRs
             // RUN: register group j (rows 8 j .. 8 j + 7) holds the quarter (j - tpos) % 4 of the frame
@@ -372,24 +403,29 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
                 const int wi = 8 * (((i >> 3) - ROT) & 3) + (i & 7);      // the row's place in the frame
                 C2 hw;
                 if constexpr (WREG) { hw = wreg[wi]; }
-                else { hw = *reinterpret_cast<const C2 *>(wtab + loff + 128 * wi); }
+                else if constexpr (WTAB) { hw = *reinterpret_cast<const C2 *>(wtab + loff + 128 * wi); }
+                else {
+                    const T *wp = win + loff + 128 * wi;
+                    if constexpr (FULL) { const pair_u w2 = *reinterpret_cast<const pair_u *>(wp); hw = C2{T(0.5) * w2.x, T(0.5) * w2.y}; }
+                    else { hw = C2{(128 * wi < lim) ? T(0.5) * wp[0] : T(0), (128 * wi + 1 < lim) ? T(0.5) * wp[1] : T(0)}; }
+                }
                 C2 v = pre[i];
                 if (!FULL) {                                 // keep data past the window out (0 * NaN)
-                    v.x = (128 * i < lim) ? v.x : 0.f;
-                    v.y = (128 * i + 1 < lim) ? v.y : 0.f;
+                    v.x = (128 * i < lim) ? v.x : T(0);
+                    v.y = (128 * i + 1 < lim) ? v.y : T(0);
                 }
                 v = v * hw;
                 if (MN0) { acc += v; }
                 if (i & 1) { zo[i >> 1] = v; } else { ze[i >> 1] = v; }
             }
             if (MN0) {
-                float sum = acc.x + acc.y;
+                T sum = acc.x + acc.y;
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) { sum += __shfl_xor(sum, o); }
-                const float mean = sum / (float)L;
+                const T mean = sum / (T)L;
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {
-                    const C2 mm = C2{(FULL || 128 * i < lim) ? mean : 0.f, (FULL || 128 * i + 1 < lim) ? mean : 0.f};
+                    const C2 mm = C2{(FULL || 128 * i < lim) ? mean : T(0), (FULL || 128 * i + 1 < lim) ? mean : T(0)};
                     if (i & 1) { zo[i >> 1] -= mm; } else { ze[i >> 1] -= mm; }
                 }
             }
@@ -398,7 +434,7 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
             // the windowed values are complete here: without this the products sink below the loads that
             // follow, the old and the new samples are both live, and the frame no longer fits the registers
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { asm volatile("" : "+v"(ze[i]), "+v"(zo[i])); }
+            for (int i = 0; i < 16; ++i) { pin(ze[i]); pin(zo[i]); }
         }
         // RUN: the per-lane factors of the twiddle stage come from LDS; asked for here, two transforms ahead
         // of their use (read where they are used, each of the 7 reads was waited for on the spot)
@@ -438,18 +474,18 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
             for (int bb = 0; bb < 4; ++bb) { const int k1 = 4 * q + bb; zp[bb] = (k1 < 16) ? &ze[slot16(k1)] : &zo[slot16(k1 - 16)]; }
             C2 t[4];
 #pragma unroll
-            for (int bb = 1; bb < 4; ++bb) { t[bb] = cx_mul_first<float>(*zp[bb], tb[bb]); }
+            for (int bb = 1; bb < 4; ++bb) { t[bb] = cx_mul_first<T>(*zp[bb], tb[bb]); }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int bb = 1; bb < 4; ++bb) { *zp[bb] = cx_mul_second<float>(*zp[bb], tb[bb], t[bb]); }
+            for (int bb = 1; bb < 4; ++bb) { *zp[bb] = cx_mul_second<T>(*zp[bb], tb[bb], t[bb]); }
             if (q && !(R4096_HACK & 2)) {
                 const C2 taq = (RUN && !R4096_TA_REG) ? (R4096_TA_AHEAD ? taq_r[q] : twl[64 * q + lane]) : ta[q];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int bb = 0; bb < 4; ++bb) { t[bb] = cx_mul_first<float>(*zp[bb], taq); }
+                for (int bb = 0; bb < 4; ++bb) { t[bb] = cx_mul_first<T>(*zp[bb], taq); }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int bb = 0; bb < 4; ++bb) { *zp[bb] = cx_mul_second<float>(*zp[bb], taq, t[bb]); }
+                for (int bb = 0; bb < 4; ++bb) { *zp[bb] = cx_mul_second<T>(*zp[bb], taq, t[bb]); }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -458,8 +494,8 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         for (int k1 = 1; k1 < 32; ++k1) {
             C2 &z = (k1 < 16) ? ze[slot16(k1)] : zo[slot16(k1 - 16)];
             const int q = k1 >> 2, bb = k1 & 3;
-            if (bb) { z = cx_mul<float>(z, tb[bb]); }
-            if (q) { z = cx_mul<float>(z, RUN ? twl[64 * q + lane] : ta[q]); }
+            if (bb) { z = cx_mul<T>(z, tb[bb]); }
+            if (q) { z = cx_mul<T>(z, RUN ? twl[64 * q + lane] : ta[q]); }
         }
 #endif
         // first radix-2 stage of the 64-point transforms over n2: columns n2 and n2 + 32 sit 32 lanes
@@ -472,12 +508,12 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
 #pragma unroll
             for (int k1 = 0; k1 < 16; ++k1) {
                 const C2 lo = ze[slot16(k1)], hi = zo[slot16(k1)];
-                const u2v sr = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo.x), __float_as_uint(hi.x), false, false);
-                const u2v si = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo.y), __float_as_uint(hi.y), false, false);
-                const C2 x = C2{__uint_as_float(sr.x), __uint_as_float(si.x)};
-                const C2 y = C2{__uint_as_float(sr.y), __uint_as_float(si.y)};
+                T xr, yr_, xi, yi;
+                half_swap(lo.x, hi.x, xr, yr_);
+                half_swap(lo.y, hi.y, xi, yi);
+                const C2 x = C2{xr, xi}, y = C2{yr_, yi};
                 dst[k1 * R4096_PITCH] = x + y;
-                dst[(32 + k1) * R4096_PITCH] = cx_mul<float>(x - y, wl);
+                dst[(32 + k1) * R4096_PITCH] = cx_mul<T>(x - y, wl);
             }
         }
         wave_sync();
@@ -520,19 +556,19 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
         // ---------------- split + power + store: the lane's bins k = r + 64 a, a < 16, and 2048 - k ----------------
 #if R4096_HACK & 8
         // timing only: rows at a pitch of 2048 values, every store instruction on a 256-byte boundary
-        float *y = Y + (RUN ? (long long)run_b * a.Wy + run_w0 + tpos : cur.row) * 2048;
+        T *y = Y + (RUN ? (long long)run_b * a.Wy + run_w0 + tpos : cur.row) * 2048;
 #else
-        float *y = Y + (RUN ? (long long)run_b * a.Wy + run_w0 + tpos : cur.row) * (CPLX ? 2 * F : F);
+        T *y = Y + (RUN ? (long long)run_b * a.Wy + run_w0 + tpos : cur.row) * (CPLX ? 2 * F : F);
 #endif
         const C2 *zpart = ex + pslot;                                      // Z[2048 - k] at zpart[15 - a]
-        float *yf = y + (CPLX ? 2 : 1) * lane, *yr = y + (CPLX ? 2 : 1) * (M - ((R4096_HACK & 8) ? 1 : 0) - lane);
-        [[maybe_unused]] C2 cu = C2{0.f, 0.f};
+        T *yf = y + (CPLX ? 2 : 1) * lane, *yr = y + (CPLX ? 2 : 1) * (M - ((R4096_HACK & 8) ? 1 : 0) - lane);
+        [[maybe_unused]] C2 cu = C2{T(0), T(0)};
         if constexpr (CPLX) {
             // the rotation of the run form undone: bin k times i^(ROT k) = i^(ROT r), bin 2048 - k times its conjugate
             constexpr int RC = RUN ? ROT : 0;
             const int e = (RC * lane) & 3;
-            const float sc = a.cscale;
-            cu = C2{e == 0 ? sc : (e == 2 ? -sc : 0.f), e == 1 ? sc : (e == 3 ? -sc : 0.f)};
+            const T sc = (T)a.cscale;
+            cu = C2{e == 0 ? sc : (e == 2 ? -sc : T(0)), e == 1 ? sc : (e == 3 ? -sc : T(0))};
         }
         // Four pairs at a time, stage by stage (no instruction feeds the one right behind it).  The factor of the
         // split, -i W4096^k = (-i W4096^r) W64^a, is taken in two parts: the constant W64^a in folded form (fft16.h:
@@ -547,17 +583,17 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
                 const C2 z = ze[slot16(aa)];
                 C2 zm = zpart[15 - aa];
                 if (aa == 0) { zm = (lane == 0) ? z : zm; }                // bin 0 pairs with itself
-                A[c] = cx_add_conj<float>(z, zm);
-                B[c] = cx_sub_conj<float>(z, zm);
+                A[c] = cx_add_conj<T>(z, zm);
+                B[c] = cx_sub_conj<T>(z, zm);
             }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { if (f[c].t != 0.0) { B[c] = cx_pre<float>(B[c], (float)f[c].t); } }
+            for (int c = 0; c < 4; ++c) { if (f[c].t != 0.0) { B[c] = cx_pre<T>(B[c], (T)f[c].t); } }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { t[c] = cx_mul_first<float>(B[c], ow); }
+            for (int c = 0; c < 4; ++c) { t[c] = cx_mul_first<T>(B[c], ow); }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { B[c] = cx_mul_second<float>(B[c], ow, t[c]); }
+            for (int c = 0; c < 4; ++c) { B[c] = cx_mul_second<T>(B[c], ow, t[c]); }
             // X_k = A + T, X_(2048-k) = conj(A - T), T = sig i^m B
-#define R4096_PQ(c) P[c] = cx_axpy_i<float, f[c].m>(A[c], (float)f[c].sig, B[c]); Q[c] = cx_axpy_i<float, f[c].m + 2>(A[c], (float)f[c].sig, B[c]);
+#define R4096_PQ(c) P[c] = cx_axpy_i<T, f[c].m>(A[c], (T)f[c].sig, B[c]); Q[c] = cx_axpy_i<T, f[c].m + 2>(A[c], (T)f[c].sig, B[c]);
             R4096_PQ(0) R4096_PQ(1) R4096_PQ(2) R4096_PQ(3)
 #undef R4096_PQ
             if constexpr (CPLX) {
@@ -567,13 +603,13 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
                     const int aa = 4 * G + c;
                     C2 u, v;
                     if constexpr (RC == 0) { u = P[c] * C2{cu.x, cu.x}; v = Q[c] * C2{cu.x, -cu.x}; }
-                    else { u = cx_mul<float>(P[c], cu); v = cx_mul<float>(Q[c], cu) * C2{1.f, -1.f}; }
-                    if (aa == 0) { u.y = (lane == 0) ? 0.f : u.y; v.y = (lane == 0) ? 0.f : v.y; }   // bins 0 and 2048
-                    *reinterpret_cast<float2_u *>(yf + 128 * aa) = float2_u{u.x, u.y};
-                    *reinterpret_cast<float2_u *>(yr - 128 * aa) = float2_u{v.x, v.y};
+                    else { u = cx_mul<T>(P[c], cu); v = cx_mul<T>(Q[c], cu) * C2{T(1), T(-1)}; }
+                    if (aa == 0) { u.y = (lane == 0) ? T(0) : u.y; v.y = (lane == 0) ? T(0) : v.y; }   // bins 0 and 2048
+                    *reinterpret_cast<pair_u *>(yf + 128 * aa) = pair_u{u.x, u.y};
+                    *reinterpret_cast<pair_u *>(yr - 128 * aa) = pair_u{v.x, v.y};
                 }
             } else {
-                float p[4], q[4];
+                T p[4], q[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { p[c] = norm2(P[c]); q[c] = norm2(Q[c]); }
                 if (EPI) { power_epilogue_n(p, a.epi); power_epilogue_n(q, a.epi); }
@@ -604,9 +640,9 @@ __global__ __launch_bounds__(64 * R4096_WAVES, 2) void stft_r4096_kernel(float *
             const C2 zmid = ex[0];
             if constexpr (CPLX) {
                 // bin 1024 is 2 conj Z_1024 (times i^(ROT 1024) = 1)
-                *reinterpret_cast<float2_u *>(y + 2048) = float2_u{2.0f * a.cscale * zmid.x, -2.0f * a.cscale * zmid.y};
+                *reinterpret_cast<pair_u *>(y + 2048) = pair_u{T(2) * (T)a.cscale * zmid.x, T(-2) * (T)a.cscale * zmid.y};
             }
-            float p = 4.0f * norm2(zmid);
+            T p = T(4) * norm2(zmid);
             if (EPI) { p = power_epilogue(p, a.epi); }
 #if R4096_ABLATE & 1
             asm volatile("" :: "v"(p));
@@ -708,21 +744,23 @@ hipEvent_t g_take_ev[64][R4096_SLOTS];
 bool g_take_busy[64][R4096_SLOTS];
 }  // namespace
 
-template <bool FULL, bool MN0, bool EPI, bool RUN, bool CPLX = false>
-static hipError_t launch_r4096_inst(float *Y, const float *X, const float *win, const float *tw, const R4096Args &a, hipStream_t s, unsigned *take)
+template <typename T, bool FULL, bool MN0, bool EPI, bool RUN, bool CPLX = false>
+static hipError_t launch_r4096_inst(T *Y, const T *X, const T *win, const T *tw, const R4096Args &a, hipStream_t s, unsigned *take)
 {
-    const size_t lds = (size_t)R4096_WAVES * R4096_WAVE_C * sizeof(float2) + (RUN ? (64 * 8) * sizeof(float2) : 0) + (r4096_wreg(MN0, EPI, RUN, CPLX) ? 0 : 4096 * sizeof(float));
+    constexpr int WAVES = r4096_waves<T>();
+    const size_t lds = r4096_lds(sizeof(T), WAVES, sizeof(T) == 4 && !r4096_wreg(MN0, EPI, RUN, CPLX), RUN);
+    const auto kernel = &stft_r4096_kernel<T, FULL, MN0, EPI, RUN, CPLX>;
     static LdsGrant grant;
-    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r4096_kernel<FULL, MN0, EPI, RUN, CPLX>), lds, grant); e != hipSuccess) { return e; }
-    long long grid = ((long long)a.frames + R4096_WAVES - 1) / R4096_WAVES;
-    if (grid > 256) { grid = 256; }                      // one 8-wave workgroup per CU (151 KB of LDS each)
+    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(kernel), lds, grant); e != hipSuccess) { return e; }
+    long long grid = ((long long)a.frames + WAVES - 1) / WAVES;
+    if (grid > 256) { grid = 256; }                      // one workgroup per CU (135 to 152 KB of LDS each)
     grid = (grid + 7) & ~7ll;
     R4096Args b = a;
     if (RUN && take) {
         // the caller's counters (it answers for launches that overlap)
         b.take = take;
         if (hipError_t e = hipMemsetAsync(b.take, 0, 8 * sizeof(unsigned), s); e != hipSuccess) { return e; }
-        hipLaunchKernelGGL((stft_r4096_kernel<FULL, MN0, EPI, RUN, CPLX>), dim3((unsigned)grid), dim3(64 * R4096_WAVES), lds, s, Y, X, win, tw, b);
+        hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64 * WAVES), lds, s, Y, X, win, tw, b);
         return hipGetLastError();
     }
     if (RUN) {
@@ -742,16 +780,28 @@ static hipError_t launch_r4096_inst(float *Y, const float *X, const float *win, 
         }
         b.take = g_take_base[dev] + 8 * slot;
         if (hipError_t e = hipMemsetAsync(b.take, 0, 8 * sizeof(unsigned), s); e != hipSuccess) { return e; }
-        hipLaunchKernelGGL((stft_r4096_kernel<FULL, MN0, EPI, RUN, CPLX>), dim3((unsigned)grid), dim3(64 * R4096_WAVES), lds, s, Y, X, win, tw, b);
+        hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64 * WAVES), lds, s, Y, X, win, tw, b);
         if (hipError_t e = hipGetLastError(); e != hipSuccess) { return e; }
         g_take_busy[dev][slot] = true;
         return hipEventRecord(ev, s);
     }
-    hipLaunchKernelGGL((stft_r4096_kernel<FULL, MN0, EPI, RUN, CPLX>), dim3((unsigned)grid), dim3(64 * R4096_WAVES), lds, s, Y, X, win, tw, b);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64 * WAVES), lds, s, Y, X, win, tw, b);
     return hipGetLastError();
 }
 
-hipError_t launch_stft_r4096(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, hipStream_t s, unsigned *take)
+// the run form: full window, frames at ss0 + w * 1024, where there are at least DSP_R4096_MIN_RUNS runs (default: two
+// per wave of a full grid; 0 = never)
+template <typename T>
+static bool r4096_runs(const FrameDesc &d)
+{
+    long long min_runs = 2 * 256 * r4096_waves<T>();
+    if (const char *e = getenv("DSP_R4096_MIN_RUNS")) { min_runs = atoll(e) > 0 ? atoll(e) : (1ll << 62); }
+    const long long runs = (long long)d.B * ((d.W + R4096_RUN - 1) / R4096_RUN);
+    return d.L == 4096 && d.tbl == nullptr && d.stp == 1024 && runs >= min_runs;
+}
+
+template <typename T>
+static hipError_t launch_r4096_any(T *Y, const T *X, const T *win, const T *tw, const FrameDesc &d, hipStream_t s, unsigned *take)
 {
     R4096Args a{};
     a.ldx = d.ldx; a.N = d.N; a.ss0 = d.ss0; a.rd_shift = d.rd_shift; a.tbl = d.tbl;
@@ -759,14 +809,8 @@ hipError_t launch_stft_r4096(float *Y, const float *X, const float *win, const f
     a.frames = d.B * d.W;
     a.B = d.B;
     const bool full = d.L == 4096, epi = d.epi.any();
-    // the run form: full window, frames at ss0 + w * 1024
-    // ... where there are at least DSP_R4096_MIN_RUNS runs (default: two per wave of a full grid; 0 = never)
-    long long min_runs = 2 * 256 * R4096_WAVES;
-    if (const char *e = getenv("DSP_R4096_MIN_RUNS")) { min_runs = atoll(e) > 0 ? atoll(e) : (1ll << 62); }
-    const long long runs = (long long)d.B * ((d.W + R4096_RUN - 1) / R4096_RUN);
-    const bool run = full && d.tbl == nullptr && d.stp == 1024 && runs >= min_runs;
-#define DSP_R4096(F_, M_, E_, R_) launch_r4096_inst<F_, M_, E_, R_>(Y, X, win, tw, a, s, take)
-    if (run) {
+#define DSP_R4096(F_, M_, E_, R_) launch_r4096_inst<T, F_, M_, E_, R_>(Y, X, win, tw, a, s, take)
+    if (r4096_runs<T>(d)) {
         if (d.mn0) { return epi ? DSP_R4096(true, true, true, true) : DSP_R4096(true, true, false, true); }
         return epi ? DSP_R4096(true, false, true, true) : DSP_R4096(true, false, false, true);
     }
@@ -779,27 +823,42 @@ hipError_t launch_stft_r4096(float *Y, const float *X, const float *win, const f
 #undef DSP_R4096
 }
 
+hipError_t launch_stft_r4096(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, hipStream_t s, unsigned *take)
+{
+    return launch_r4096_any<float>(Y, X, win, tw, d, s, take);
+}
+hipError_t launch_stft_r4096(double *Y, const double *X, const double *win, const double *tw, const FrameDesc &d, hipStream_t s, unsigned *take)
+{
+    return launch_r4096_any<double>(Y, X, win, tw, d, s, take);
+}
+
 // The complex form: Y[b][w][2049] interleaved (re, im) pairs times `scale`; equally spaced frames, no mean removal.
 bool r4096_cplx_supported(const FrameDesc &d)
 {
     return r4096_supported(d) && d.tbl == nullptr && !d.mn0 && !d.epi.any() && (long long)d.B * d.wy() < (1ll << 30);
 }
 
-hipError_t launch_stft_r4096_cplx(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, double scale, hipStream_t s)
+template <typename T>
+static hipError_t launch_r4096_cplx_any(T *Y, const T *X, const T *win, const T *tw, const FrameDesc &d, double scale, hipStream_t s)
 {
     R4096Args a{};
     a.ldx = d.ldx; a.N = d.N; a.ss0 = d.ss0; a.rd_shift = d.rd_shift; a.tbl = nullptr;
     a.L = d.L; a.W = d.W; a.Wy = d.wy(); a.stp = d.stp; a.edge = d.edge; a.epi = d.epi;
     a.frames = d.B * d.W;
     a.B = d.B;
-    a.cscale = (float)scale;
-    const bool full = d.L == 4096;
-    long long min_runs = 2 * 256 * R4096_WAVES;
-    if (const char *e = getenv("DSP_R4096_MIN_RUNS")) { min_runs = atoll(e) > 0 ? atoll(e) : (1ll << 62); }
-    const long long runs = (long long)d.B * ((d.W + R4096_RUN - 1) / R4096_RUN);
-    if (full && d.stp == 1024 && runs >= min_runs) { return launch_r4096_inst<true, false, false, true, true>(Y, X, win, tw, a, s, nullptr); }
-    if (full) { return launch_r4096_inst<true, false, false, false, true>(Y, X, win, tw, a, s, nullptr); }
-    return launch_r4096_inst<false, false, false, false, true>(Y, X, win, tw, a, s, nullptr);
+    a.cscale = scale;
+    if (r4096_runs<T>(d)) { return launch_r4096_inst<T, true, false, false, true, true>(Y, X, win, tw, a, s, nullptr); }
+    if (d.L == 4096) { return launch_r4096_inst<T, true, false, false, false, true>(Y, X, win, tw, a, s, nullptr); }
+    return launch_r4096_inst<T, false, false, false, false, true>(Y, X, win, tw, a, s, nullptr);
+}
+
+hipError_t launch_stft_r4096_cplx(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, double scale, hipStream_t s)
+{
+    return launch_r4096_cplx_any<float>(Y, X, win, tw, d, scale, s);
+}
+hipError_t launch_stft_r4096_cplx(double *Y, const double *X, const double *win, const double *tw, const FrameDesc &d, double scale, hipStream_t s)
+{
+    return launch_r4096_cplx_any<double>(Y, X, win, tw, d, scale, s);
 }
 
 }  // namespace dsp

@@ -403,8 +403,8 @@ bool wave_fft_supported(const FrameDesc &d)
 {
     const int n = d.nfft;
     if (n < 16 || (n & (n - 1)) != 0 || d.L < 1 || d.L > n) { return false; }
-    if (sizeof(T) == 4 && n == 4096) { return false; }   // has a kernel of its own
-    return n <= (sizeof(T) == 4 ? 8192 : 4096);
+    if (n == 4096) { return false; }                     // has a kernel of its own (stft_r4096_kernel)
+    return n <= (sizeof(T) == 4 ? 8192 : 2048);
 }
 
 template <typename T>
@@ -419,9 +419,6 @@ hipError_t launch_stft_wave(T *Y, const T *X, const T *win, const T *tw, const F
     case 512: return launch_wave_inst<T, 512>(Y, X, win, tw, d, s);
     case 1024: return launch_wave_inst<T, 1024>(Y, X, win, tw, d, s);
     case 2048: return launch_wave_inst<T, 2048>(Y, X, win, tw, d, s);
-    case 4096:                                            // float32: stft_r4096_kernel
-        if constexpr (sizeof(T) == 8) { return launch_wave_inst<T, 4096>(Y, X, win, tw, d, s); }
-        return hipErrorInvalidValue;
     case 8192:
         if constexpr (sizeof(T) == 4) { return launch_wave_inst<T, 8192>(Y, X, win, tw, d, s); }
         return hipErrorInvalidValue;

@@ -307,6 +307,7 @@ int family_of(size_t nfft)
     if (!is_pow2(nfft)) { return 1; }
     if (nfft == 512 && !tl_force_generic) { return 3; }
     if (nfft == 4096 && !tl_force_generic) { return 4; }
+    if (nfft == 8192 && sizeof(T) == 4 && !tl_force_generic) { return 8; }
     if ((nfft == 1024 || nfft == 2048) && !tl_force_generic) { return 6; }
     if ((nfft == 256 || nfft == 128 || nfft == 64) && !tl_force_generic) { return 7; }
     if (!tl_force_generic && nfft <= (1u << 20)) {
@@ -354,6 +355,12 @@ int run_fused(const char *fn, int dev, T *Yd, const T *Xd, const T *wd, const Fr
     if (fam == 4 && r4096_supported(d)) {
         HIPCHK(fn, launch_stft_r4096(Yd, Xd, wd, tw, d, s, take));
         return 0;
+    }
+    if constexpr (sizeof(T) == 4) {
+        if (fam == 8 && r8192_supported(d)) {
+            HIPCHK(fn, launch_stft_r8192(Yd, Xd, wd, tw, d, s));
+            return 0;
+        }
     }
     if (fam == 6 && r512x_supported(d)) {
         HIPCHK(fn, launch_stft_r512x(Yd, Xd, wd, tw, d, s));

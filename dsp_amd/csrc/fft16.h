@@ -174,6 +174,32 @@ constexpr double sin_tab(int k, int n) { return cos_tab(k * (64 / n) - 16, 64); 
 // the twiddle W_N^K = exp(-2 pi i K / N) in folded form
 constexpr TwF twf_n(int k, int n) { return twf(cos_tab(k, n), -sin_tab(k, n)); }
 
+// The same for any N divisible by 8, the constants from a Taylor series evaluated at compile time (argument at most
+// pi/4, 11 terms: below 1e-17 absolute)
+constexpr double ct_sin_small(double x)
+{
+    double term = x, sum = x;
+    for (int i = 1; i <= 11; ++i) { term *= -x * x / ((2 * i) * (2 * i + 1)); sum += term; }
+    return sum;
+}
+constexpr double ct_cos_small(double x)
+{
+    double term = 1.0, sum = 1.0;
+    for (int i = 1; i <= 11; ++i) { term *= -x * x / ((2 * i - 1) * (2 * i)); sum += term; }
+    return sum;
+}
+struct CosSin { double c, s; };
+constexpr CosSin cos_sin_ct(int k, int n)                   // (cos, sin)(2 pi k / n)
+{
+    const int j = ((k % n) + n) % n, q = n / 4;
+    const int quad = j / q, rem = j % q;
+    const bool low = 2 * rem <= q;
+    const double th = 2.0 * cx_pi * (low ? rem : q - rem) / n;
+    const double c = low ? ct_cos_small(th) : ct_sin_small(th), s = low ? ct_sin_small(th) : ct_cos_small(th);
+    return quad == 0 ? CosSin{c, s} : quad == 1 ? CosSin{-s, c} : quad == 2 ? CosSin{-c, -s} : CosSin{s, -c};
+}
+constexpr TwF twf_ct(int k, int n) { const CosSin w = cos_sin_ct(k, n); return twf(w.c, -w.s); }
+
 // radix-4 butterfly on a0 and the products w1 a1, w2 a2, w3 a3 (w_j = W_N^(K_j)), outputs in natural order in a0..a3
 template <typename T, int N, int K1, int K2, int K3>
 __device__ __forceinline__ void dft4c_tw(cx<T> &a0, cx<T> &a1, cx<T> &a2, cx<T> &a3)

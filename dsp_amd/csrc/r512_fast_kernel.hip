@@ -707,7 +707,7 @@ static hipError_t launch_stft_r512_fast_one(T *Y, const T *X, const T *win, cons
     const bool epi = d.epi.any();
     // float, equally spaced frames: spans by LDS-DMA (the double kernel's exchange tiles leave no LDS for span slots)
     constexpr bool RING = sizeof(T) == 4 && R512F_RING_F32;
-    const bool wide = 3 * d.stp + 512 > 1024 || (d.stp & 1);   // spans of more than 1024 samples (20 staged elements per lane), odd hops
+    [[maybe_unused]] const bool wide = 3 * d.stp + 512 > 1024 || (d.stp & 1);   // spans of more than 1024 samples (20 staged elements per lane), odd hops
     const bool nr13 = d.L > 384 && d.L <= 416;               // windows that leave the last three rows of pass 1 empty (400: 25 ms at 16 kHz)
 #define DSP_R512F(NR_, MN0_, EPI_) launch_fast_inst<T, NR_, MN0_, EPI_, 0, false, RING>(Y, X, win, tw, a, s)
 #define DSP_R512W(NR_, MN0_, EPI_) launch_fast_inst<T, NR_, MN0_, EPI_, 1, false, RING>(Y, X, win, tw, a, s)
@@ -782,7 +782,7 @@ hipError_t launch_stft_r512_fast_cplx(T *Y, const T *X, const T *win, const T *t
     a.all16 = (d.W % 4 == 0) && (d.wy() % 4 == 0) && (reinterpret_cast<uintptr_t>(Y) % 16 == 0);
     a.Wy = d.wy();
     constexpr bool RING = sizeof(T) == 4 && R512F_RING_F32;
-    const bool wide = 3 * d.stp + 512 > 1024 || (d.stp & 1);
+    [[maybe_unused]] const bool wide = 3 * d.stp + 512 > 1024 || (d.stp & 1);
     const bool nr13 = d.L > 384 && d.L <= 416;
     if (3 * d.stp + 512 > 1280) { return launch_fast_inst<T, 16, false, false, 2, false, RING, true>(Y, X, win, tw, a, s); }
     if (wide) {

@@ -220,6 +220,9 @@ bool r4096_supported(const FrameDesc &d);
 // take: 8 counters (32 bytes of device memory) for the run form, or nullptr for the library's own sets
 hipError_t launch_stft_r4096(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, hipStream_t s, unsigned *take = nullptr);
 hipError_t launch_stft_r4096(double *Y, const double *X, const double *win, const double *tw, const FrameDesc &d, hipStream_t s, unsigned *take = nullptr);   // 4 waves per workgroup
+// nfft 8192, float32 (r8192_kernel.hip)
+bool r8192_supported(const FrameDesc &d);
+hipError_t launch_stft_r8192(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, hipStream_t s);
 // nfft 1024 and 2048, float32, equally spaced frames (r512x_kernel.hip)
 bool r512x_supported(const FrameDesc &d);
 hipError_t launch_stft_r512x(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, hipStream_t s);

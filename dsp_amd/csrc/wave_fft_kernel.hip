@@ -32,9 +32,8 @@ constexpr int wave_cap(int M, int elem) { return M / 64 < 4 ? 4 : (M / 64 > (ele
 constexpr int wave_radix(int rem, int cap) { return rem < cap ? rem : cap; }
 // lanes that share a frame: the whole wave from M = 256 on (float64: 128, measured); below, M / 4 (the butterflies of a radix-4
 // pass), at least 8: a wave then transforms 2 to 8 short frames side by side instead of idling lanes
-// The longest transforms (float32 from nfft 4096, float64 from 2048: a wave alone has neither the registers
-// nor the LDS for them) take a whole workgroup of 256 threads per frame, with workgroup barriers between the
-// passes.
+// The longest transform left to this kernel (float64 nfft 2048: a wave alone has neither the registers nor the LDS
+// for it) takes a whole workgroup of 256 threads per frame, with workgroup barriers between the passes.
 constexpr bool wave_wg(int M, int elem) { return M * elem >= 8192; }
 constexpr int wave_gl(int M, int elem) { return wave_wg(M, elem) ? 256 : ((M >= 256 || (elem == 8 && M >= 128)) ? 64 : (M / 4 < 8 ? 8 : M / 4)); }
 template <int GL> __device__ __forceinline__ void frame_sync() { if constexpr (GL > 64) { __syncthreads(); } else { wave_sync(); } }
@@ -403,8 +402,7 @@ bool wave_fft_supported(const FrameDesc &d)
 {
     const int n = d.nfft;
     if (n < 16 || (n & (n - 1)) != 0 || d.L < 1 || d.L > n) { return false; }
-    if (n == 4096) { return false; }                     // has a kernel of its own (stft_r4096_kernel)
-    return n <= (sizeof(T) == 4 ? 8192 : 2048);
+    return n <= 2048;                                    // 4096 and float32 8192 have kernels of their own
 }
 
 template <typename T>
@@ -419,9 +417,6 @@ hipError_t launch_stft_wave(T *Y, const T *X, const T *win, const T *tw, const F
     case 512: return launch_wave_inst<T, 512>(Y, X, win, tw, d, s);
     case 1024: return launch_wave_inst<T, 1024>(Y, X, win, tw, d, s);
     case 2048: return launch_wave_inst<T, 2048>(Y, X, win, tw, d, s);
-    case 8192:
-        if constexpr (sizeof(T) == 4) { return launch_wave_inst<T, 8192>(Y, X, win, tw, d, s); }
-        return hipErrorInvalidValue;
     default: return hipErrorInvalidValue;
     }
 }

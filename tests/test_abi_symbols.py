@@ -51,7 +51,7 @@ def test_num_frames_host_logic():
     assert dsp_amd.num_frames(172800000, 4096, 1024, False) == 168750
     assert dsp_amd.num_frames(100, 400, 160, True) == 0
     assert dsp_amd.kernel_family(512, np.float32) == 3
-    assert dsp_amd.kernel_family(4096, np.float64) == 4 and dsp_amd.kernel_family(8192, np.float64) == 2
+    assert dsp_amd.kernel_family(4096, np.float64) == 4 and dsp_amd.kernel_family(8192, np.float64) == 2 and dsp_amd.kernel_family(8192, np.float32) == 8
     assert dsp_amd.kernel_family(256, np.float32) == 7 and dsp_amd.kernel_family(256, np.float64) == 7 and dsp_amd.kernel_family(1024, np.float64) == 6
     assert dsp_amd.kernel_family(1024, np.float32) == 6 and dsp_amd.kernel_family(2048, np.float64) == 6 and dsp_amd.kernel_family(32, np.float64) == 5
     assert dsp_amd.kernel_family(16384, np.float32) == 2

@@ -174,13 +174,13 @@ def test_both_512_families_agree_with_oracle(O, D, dt):
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 def test_both_power_of_two_families_agree_with_oracle(O, D, dt):
-    """Power-of-two nfft: the Stockham kernels (family 5: nfft 16 to 8192 float32 / 2048 float64; one wave, part of a
-    wave or a workgroup per frame; 64 to 4096 have kernels of their own in front of it) and the generic kernel
+    """Power-of-two nfft: the Stockham kernels (family 5: nfft 16 to 2048; one wave, part of a wave or a workgroup per
+    frame; 64 to 4096 and float32 8192 have kernels of their own in front of it) and the generic kernel
     (family 2) must each meet the bound:
     every size, short and odd windows, odd hops, a signal shorter than the window, every flag."""
     top = 8192 if dt == np.float32 else 4096
     assert D.kernel_family(16, dt) == 5 and D.kernel_family(2 * top, dt) == 2
-    assert D.kernel_family(8192, dt) == (5 if dt == np.float32 else 2)
+    assert D.kernel_family(8192, dt) == (8 if dt == np.float32 else 2)
     cases = [(nfft, nfft, max(1, nfft // 4), (0, 0, 0)) for nfft in (16, 32, 64, 128, 256, 1024, 2048, 4096, 8192) if nfft <= top]
     cases += [(top, top - 37, top // 3 + 1, (1, 1, 0)), (2048, 1500, 511, (1, 0, 1))]
     cases += [(16, 9, 3, (1, 0, 0)), (64, 33, 7, (0, 1, 0)), (256, 200, 80, (1, 1, 1)), (1024, 801, 321, (1, 0, 1)),
@@ -445,6 +445,62 @@ def test_both_4096_families_agree_with_oracle(O, D, dt):
                 rc, Yref = O.stft_flt(x.astype(np.float64), win.astype(np.float64), W, c0, stp, 4096, 0, 0, 0, intended=intended, exact=False)
                 assert rc == 0
                 Y = D.stft_flt(x, win, W, c0, stp, nfft=4096)
+                check_spec(O, Y, Yref.astype(dt))
+        finally:
+            D.set_flt_mode(False)
+
+
+def test_8192_kernel_agrees_with_oracle(O, D):
+    """nfft 8192 (float32) has a register-resident kernel (a 64 x 64 transform per wave, 4 waves per workgroup): full
+    and short windows, odd hops (unaligned frame starts), a signal shorter than the window, every flag, a batch with
+    outputs at every 4-byte alignment and untouched neighbours, bit-equal repeats on a full grid, and the zero-edged
+    stft_flt framings (tables included)."""
+    import torch
+    dt = np.float32
+    assert D.kernel_family(8192, dt) == 8
+    for (N, L, stp, flags) in [(70000, 8192, 2048, (0, 0, 0)), (70001, 8192, 2047, (1, 0, 0)), (60000, 6000, 1400, (0, 1, 0)),
+                               (60000, 4097, 1024, (1, 1, 1)), (6000, 8192, 2048, (0, 0, 1)), (40000, 100, 9000, (1, 0, 0)),
+                               (9000, 8191, 1, (0, 0, 0)), (50000, 8192, 4096, (1, 1, 0))]:
+        x = signal(N + L, N, dt) + dt(0.2)
+        win = D.blackmanharris(L, dt) if L > 5000 else D.povey(L, dt)
+        if stp == 1:
+            x = x[:8300]
+        for snip in (0, 1):
+            if snip and L > len(x):
+                continue
+            rc, Yref = O.stft(x.astype(np.float64), win.astype(np.float64), stp, 8192, snip, *flags, exact=False)
+            assert rc == 0
+            Y = D.stft(x, win, stp, bool(snip), *[bool(f) for f in flags], nfft=8192)
+            check_spec(O, Y, Yref.astype(dt), flags[1], flags[2])
+    xs = np.stack([signal(10 * k + 8192, 50000, dt) for k in range(3)])
+    win = D.hann(8192, dt)
+    want = np.stack([O.stft(r.astype(np.float64), win.astype(np.float64), 2048, 8192, 0, exact=False)[1] for r in xs]).astype(dt)
+    xd, wd = torch.from_numpy(xs).cuda(), torch.from_numpy(win).cuda()
+    for off in (0, 1, 2, 3):
+        buf = torch.full((want.size + 8,), 7.0, dtype=torch.float32, device="cuda")
+        out = buf[off:off + want.size].view(want.shape)
+        D.stft_dev(xd, wd, 2048, nfft=8192, out=out)
+        torch.cuda.synchronize()
+        check_spec(O, out.cpu().numpy(), want)
+        assert float(buf[:off].sum()) == 7.0 * off and bool((buf[off + want.size:] == 7.0).all())
+    xd = torch.randn((16, 1 << 21), device="cuda", generator=torch.Generator(device="cuda").manual_seed(8192))
+    y0 = D.stft_dev(xd, wd, 2048, nfft=8192)
+    y1 = torch.empty_like(y0)
+    for _ in range(5):
+        D.stft_dev(xd, wd, 2048, nfft=8192, out=y1)
+        assert torch.equal(y0, y1)
+    alone = D.stft_dev(xd[11:12].clone(), wd, 2048, nfft=8192)
+    assert torch.equal(alone[0], y0[11])
+    del xd, y0, y1
+    x = signal(79, 60000, dt)
+    win = D.blackmanharris(8192, dt)
+    for intended in (False, True):
+        D.set_flt_mode(intended)
+        try:
+            for (c0, stp, W) in [(0.0, 2048.0, 30), (3000.0, 2000.5, 20), (-12000.0, 4096.0, 20)]:
+                rc, Yref = O.stft_flt(x.astype(np.float64), win.astype(np.float64), W, c0, stp, 8192, 0, 0, 0, intended=intended, exact=False)
+                assert rc == 0
+                Y = D.stft_flt(x, win, W, c0, stp, nfft=8192)
                 check_spec(O, Y, Yref.astype(dt))
         finally:
             D.set_flt_mode(False)

@@ -234,6 +234,9 @@ hipError_t launch_stft_r256(double *Y, const double *X, const double *win, const
 template <typename T> bool wave_fft_supported(const FrameDesc &d);
 template <typename T> hipError_t launch_stft_wave(T *Y, const T *X, const T *win, const T *tw, const FrameDesc &d, hipStream_t s);
 template <typename T> hipError_t launch_stft_r512_fast(T *Y, const T *X, const T *win, const T *tw, const FrameDesc &d, hipStream_t s);
+// nfft 512, float32: the d.B signals are adjacent channels of a [N][pitch] array (sample n of channel c at X[n pitch + c]), read in place
+bool r512_fast_ilv_supported(const FrameDesc &d, const float *X, size_t pitch);
+hipError_t launch_stft_r512_fast_ilv(float *Y, const float *X, const float *win, const float *tw, const FrameDesc &d, size_t pitch, hipStream_t s);
 bool r512_fast_cplx_supported(const FrameDesc &d);
 bool r512x_cplx_supported(const FrameDesc &d);
 bool r256_cplx_supported(const FrameDesc &d);

@@ -206,7 +206,7 @@ int dsp_stft_flt_set_mode (const int intended);
  * The first use of an nfft on a device builds its twiddle table (an allocation and a blocking copy; the first use
  * of a non-integral stft_flt framing likewise builds its table of frame starts); calls after that only enqueue.
  * Every entry point of this library returns, for a given signal, values that depend on that signal and the
- * arguments only: the host-pointer, batched, strided and multi-GPU forms give the same bits as this one (the
+ * arguments only: the host-pointer, batched, strided (but see the in-place case there) and multi-GPU forms give the same bits as this one (the
  * allocation-free form computes its twiddle tables on the device instead of taking the host's: the same values
  * unless a table entry lies within 1e-16 of a rounding boundary, so equal bits in practice, the tolerance of the
  * path by contract).  One exception: nfft 4096 with a full window and hop 1024 walks a signal in runs of 32 frames when the
@@ -235,7 +235,12 @@ int dsp_stft_flt_batch_dev_d (double *Y_dev, const double *X_dev, const double *
  * tensor with interleaved channels (row-major [N][C]: the reference's tensors have stride K along the
  * transformed axis, c/fft.fftw.r2hc.c:63-65) is B = C, ldx = 1, incx = C.  The signals are first gathered into a
  * dense [B][N] buffer that lives for the call (allocated and freed in `stream`'s order, B*N elements), so the
- * output has the bits of the dense entry point; incx = 1 is the dense entry point itself. */
+ * output has the bits of the dense entry point; incx = 1 is the dense entry point itself.
+ * One case is read in place, without the buffer: dsp_stft_batch_dev_strided_s with nfft 512 on 4, 8, ... 32 adjacent
+ * channels (ldx = 1, B and incx multiples of 4, X_dev 16-byte aligned), where the kernel fetches one frame of 4
+ * channels per step (2 to 3.5 times faster than the gather up to 16 channels, equal at 32).  Its values agree with
+ * the dense entry point's to rounding (for windows of 385 to 416 samples the dense kernel is another instantiation);
+ * the environment variable DSP_ILV_MAX_CHANNELS moves the limit of 32 (0: always gather). */
 int dsp_stft_batch_dev_strided_s (float *Y_dev, const float *X_dev, const float *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t incx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, void *stream);
 int dsp_stft_batch_dev_strided_d (double *Y_dev, const double *X_dev, const double *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t incx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg, void *stream);
 int dsp_stft_flt_batch_dev_strided_s (float *Y_dev, const float *X_dev, const float *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t incx, const size_t L, const size_t W, const size_t nfft, const float c0, const float stp, const int mn0, const int amp, const int lg, void *stream);
@@ -244,7 +249,7 @@ int dsp_stft_flt_batch_dev_strided_d (double *Y_dev, const double *X_dev, const 
 /* The complex spectrogram of B signals: the frames of stft (same W, same edge reflection) times the window, then the
  * real FFT of each as fft_fftw_r2hc_s/_d returns it: Y[b][w][F] interleaved (re, im) pairs, F = nfft/2+1, the imaginary
  * parts of bins 0 and nfft/2 zero; sc != 0 scales by 1/sqrt(2 nfft) (reference c/window_univar.c:41-89 followed by
- * c/fft.fftw.r2hc.c:24-109 along the frames, fused).  nfft 64 / 128 / 256 / 512 / 1024 / 2048 (and float32 nfft 4096) run on the
+ * c/fft.fftw.r2hc.c:24-109 along the frames, fused).  nfft 64 / 128 / 256 / 512 / 1024 / 2048 / 4096 run on the
  * fused kernels (the rows leave as complex values instead of powers), anything else on the unfused kernels. */
 int dsp_stft_cplx_batch_dev_s (float *Y_dev, const float *X_dev, const float *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int sc, void *stream);
 int dsp_stft_cplx_batch_dev_d (double *Y_dev, const double *X_dev, const double *win_dev, const size_t B, const size_t N, const size_t ldx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int sc, void *stream);
@@ -264,7 +269,8 @@ int dsp_stft_flt_batch_d (double *Y, const double *X, const double *win, const s
 /* Host-pointer forms for signals with a sample stride (sample n of signal b at X[b*ldx + n*incx]): what the tools call
  * for a multivariate file whose channels are interleaved (row-major [N][C]: B = C, ldx = 1, incx = C; the layout of
  * c/fft.fftw.r2hc.c:63-65).  The span of X that holds the signals is copied to the device as it lies, the signals are
- * gathered there, Y[b][W][F] comes back dense.  incx = 1 is dsp_stft_batch_s/_d and dsp_stft_flt_batch_s/_d. */
+ * gathered there (or read in place, as dsp_stft_batch_dev_strided_s describes), Y[b][W][F] comes back dense.  incx = 1
+ * is dsp_stft_batch_s/_d and dsp_stft_flt_batch_s/_d. */
 int dsp_stft_batch_strided_s (float *Y, const float *X, const float *win, const size_t B, const size_t N, const size_t ldx, const size_t incx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg);
 int dsp_stft_batch_strided_d (double *Y, const double *X, const double *win, const size_t B, const size_t N, const size_t ldx, const size_t incx, const size_t L, const size_t nfft, const size_t stp, const int snip_edges, const int mn0, const int amp, const int lg);
 int dsp_stft_flt_batch_strided_s (float *Y, const float *X, const float *win, const size_t B, const size_t N, const size_t ldx, const size_t incx, const size_t L, const size_t W, const size_t nfft, const float c0, const float stp, const int mn0, const int amp, const int lg);

@@ -829,12 +829,15 @@ def test_batch_host_streamed_equals_device(O, D, dt):
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
-def test_interleaved_channels_equal_channels_alone(O, D, dt):
+def test_interleaved_channels_equal_channels_alone(O, D, dt, monkeypatch):
     """A multivariate tensor with interleaved channels, row-major [N][C] (sample stride C, channel stride 1: the
     reference's tensors have stride K along the transformed axis, c/fft.fftw.r2hc.c:63-65), through the strided
-    entry points: every channel has the bits of the same channel transformed from a dense copy, and matches the
-    oracle; channel counts that are no multiple of the gather tile, a sub-block of the channels, both framings."""
+    entry points with the channels gathered into a dense batch first: every channel has the bits of the same channel
+    transformed from a dense copy, and matches the oracle; channel counts that are no multiple of the gather tile, a
+    sub-block of the channels, both framings.  (The in-place read of the 512-point kernel is switched off here; it has
+    a test of its own below.)"""
     import torch
+    monkeypatch.setenv("DSP_ILV_MAX_CHANNELS", "0")
     tdt = torch.float32 if dt == np.float32 else torch.float64
     g = torch.Generator(device="cuda").manual_seed(17)
     win = torch.from_numpy(D.povey(400, dt)).cuda()
@@ -857,6 +860,58 @@ def test_interleaved_channels_equal_channels_alone(O, D, dt):
         c = Cc - 1
         rc, Yref = O.stft(dense[c].cpu().numpy(), win.cpu().numpy(), 160, 512, exact=False)
         check_spec(O, Y[c].cpu().numpy(), Yref)
+
+
+def test_interleaved_channels_read_in_place(O, D, monkeypatch):
+    """float32, nfft 512, up to 32 adjacent channels of a [N][pitch] array whose count and pitch are multiples of 4: the
+    512-point kernel reads them in place (a step = one frame of 4 channels).  Against the oracle channel by channel and
+    against the gather + dense path (same values to rounding: another instantiation of the kernel): full, short and
+    odd windows, hops up to and past 512, both edge rules, every flag, a signal shorter than the window, a block of
+    the channels of a wider array, the bytes around the output untouched; and what is not eligible (a channel count
+    that is no multiple of 4, an unaligned block) still takes the gather and gives the dense bits."""
+    import torch
+    dt = np.float32
+    g = torch.Generator(device="cuda").manual_seed(23)
+    cases = [(48000, 64, 400, 160, 0, (0, 0, 0)), (20000, 8, 512, 128, 1, (1, 0, 0)), (9001, 12, 333, 77, 0, (0, 1, 1)),
+             (30000, 4, 400, 600, 1, (1, 1, 0)), (300, 16, 400, 160, 0, (0, 0, 1)), (16000, 32, 1, 512, 0, (0, 0, 0)),
+             (7000, 20, 512, 1, 1, (0, 1, 0))]
+    for (N, Cc, L, hop, snip, flags) in cases:
+        if hop == 1:
+            N = 700
+        t = torch.randn((N, Cc), generator=g, device="cuda") * 0.3 + 0.1
+        x = t.T
+        win = torch.from_numpy(D.povey(L, dt)).cuda()
+        kw = dict(snip_edges=bool(snip), mn0=bool(flags[0]), amp=bool(flags[1]), lg=bool(flags[2]), nfft=512)
+        monkeypatch.setenv("DSP_ILV_MAX_CHANNELS", "0")
+        want = D.stft_dev(x, win, hop, **kw)
+        monkeypatch.setenv("DSP_ILV_MAX_CHANNELS", "64")       # (the default limit is 32 channels)
+        buf = torch.full((want.numel() + 8,), 7.0, device="cuda")
+        out = buf[4:4 + want.numel()].view(want.shape)
+        D.stft_dev(x, win, hop, out=out, **kw)
+        torch.cuda.synchronize()
+        assert bool((buf[:4] == 7.0).all()) and bool((buf[4 + want.numel():] == 7.0).all())
+        if 384 < L <= 416 and hop <= 170:
+            # the dense kernel has an instantiation of its own for these windows and hops (13 of 16 rows of pass 1 hold data), the in-place
+            # form does not: equal to rounding, not to the bit -- which also shows that the in-place form is what ran
+            assert not torch.equal(out, want)
+        check_spec(O, out.cpu().numpy().reshape(-1, 257), want.cpu().numpy().reshape(-1, 257), flags[1], flags[2])
+        for c in (0, Cc - 1):
+            rc, Yref = O.stft(t[:, c].cpu().numpy().copy(), win.cpu().numpy(), hop, 512, snip, *flags, exact=False)
+            assert rc == 0
+            check_spec(O, out[c].cpu().numpy(), Yref, flags[1], flags[2])
+    # a block of 8 channels of a 24-channel array (pitch 24), and what falls back to the gather
+    monkeypatch.delenv("DSP_ILV_MAX_CHANNELS")
+    t = torch.randn((12000, 24), generator=g, device="cuda")
+    x = t.T
+    win = torch.from_numpy(D.hann(400, dt)).cuda()
+    dense = D.stft_dev(x.contiguous(), win, 160)
+    blk = D.stft_dev(x[8:16], win, 160)
+    check_spec(O, blk.cpu().numpy().reshape(-1, 257), dense[8:16].cpu().numpy().reshape(-1, 257))
+    assert not torch.equal(blk, dense[8:16])
+    assert torch.equal(D.stft_dev(x[1:9], win, 160), dense[1:9])          # not on a 16-byte boundary: gathered
+    assert torch.equal(D.stft_dev(x[4:10], win, 160), dense[4:10])        # 6 channels: gathered
+    monkeypatch.setenv("DSP_ILV_MAX_CHANNELS", "4")
+    assert torch.equal(D.stft_dev(x[8:16], win, 160), dense[8:16])        # above the limit: gathered
 
 
 def test_multi_gpu_entry_points_on_one_device(O, D):
@@ -1048,12 +1103,16 @@ def test_bench_two_rank_rehearsal_in_a_fresh_process():
     import json
     import subprocess
     import sys
+    import socket
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, DSP_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    with socket.socket() as sk:                      # a port nobody listens on (a fixed one may be taken on a shared host)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29577", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
            "--workload", "utt1024x10s_f32_hann400_hop160_nfft512", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=root)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=150, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]

@@ -95,8 +95,20 @@ template <typename T> __device__ __forceinline__ cx<T> cx_mul(const cx<T> a, con
 // fma that consumes the packed product issued just before it costs an extra s_nop
 template <typename T> __device__ __forceinline__ cx<T> cx_mul_first(const cx<T> a, const cx<T> w) { return a * cx<T>{w.x, w.x}; }
 template <typename T> __device__ __forceinline__ cx<T> cx_mul_second(const cx<T> a, const cx<T> w, const cx<T> t) { return cx_fma(cx_swap(a), cx<T>{-w.y, w.y}, t); }
-// |a|^2
-template <typename T> __device__ __forceinline__ T cx_norm(const cx<T> a) { const cx<T> q = a * a; return q.x + q.y; }
+// |a|^2: the packed square and the add of its halves.  (DSP_NORM_FMA 1: a plain multiply and a plain fma instead, which the
+// 4096-point kernel uses (norm2 there, measured faster); in the 512-, 1024- and 2048-point kernels it measured 2.5 / 4 / 2.5 %
+// slower.)
+#ifndef DSP_NORM_FMA
+#define DSP_NORM_FMA 0
+#endif
+template <typename T> __device__ __forceinline__ T cx_norm(const cx<T> a)
+{
+#if DSP_NORM_FMA
+    return __builtin_fma(a.y, a.y, a.x * a.x);
+#else
+    const cx<T> q = a * a; return q.x + q.y;
+#endif
+}
 
 template <typename T, bool Z3 = false>
 __device__ __forceinline__ void dft4c(cx<T> &a0, cx<T> &a1, cx<T> &a2, cx<T> &a3)

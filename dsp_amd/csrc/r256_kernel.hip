@@ -240,6 +240,8 @@ __global__ __launch_bounds__(64 * r256_waves<T>(), sizeof(T) == 4 ? 2 : 1) void 
 
         // ---- pass 1: lane (frame f, column j): 16-point FFT over the rows ----
         C zz[16];
+        int lim = L - 2 * j;                              // element c of the pair in row n1 is inside the window iff 2 CL n1 + c < lim
+        if constexpr (DSP_MASK_RECOMPUTE && NR == 16) { asm volatile("" : "+v"(lim)); }
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
             if (n1 < NR) {
@@ -247,9 +249,8 @@ __global__ __launch_bounds__(64 * r256_waves<T>(), sizeof(T) == 4 ? 2 : 1) void 
                 if constexpr (ALN) { const pair_a t = *reinterpret_cast<const pair_a *>(xrow + 2 * CL * n1); v = C{t.x, t.y}; }
                 else { const pair_u t = *reinterpret_cast<const pair_u *>(xrow + 2 * CL * n1); v = C{t.x, t.y}; }
                 if (NR == 16 || n1 == NR - 1) {            // rows that may reach past the window: keep that data out (0 * NaN)
-                    const int l = 2 * CL * n1 + 2 * j;
-                    v.x = (l < L) ? v.x : T(0);
-                    v.y = (l + 1 < L) ? v.y : T(0);
+                    v.x = (2 * CL * n1 < lim) ? v.x : T(0);
+                    v.y = (2 * CL * n1 + 1 < lim) ? v.y : T(0);
                 }
                 zz[n1] = v * hw[n1];
             } else {
@@ -267,8 +268,7 @@ __global__ __launch_bounds__(64 * r256_waves<T>(), sizeof(T) == 4 ? 2 : 1) void 
 #pragma unroll
             for (int n1 = 0; n1 < NR; ++n1) {
                 if (NR == 16 || n1 == NR - 1) {
-                    const int l = 2 * CL * n1 + 2 * j;
-                    zz[n1] -= C{(l < L) ? mean : T(0), (l + 1 < L) ? mean : T(0)};
+                    zz[n1] -= C{(2 * CL * n1 < lim) ? mean : T(0), (2 * CL * n1 + 1 < lim) ? mean : T(0)};
                 } else {
                     zz[n1] -= C{mean, mean};
                 }

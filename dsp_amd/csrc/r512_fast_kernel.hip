@@ -418,6 +418,8 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
         }
         // ---- pass 1: lane (frame f, column n2 = j): 16-point FFT over the rows n1 ----
         C zz[16];
+        int lim = L - 2 * j;                              // element c of the pair in row n1 is inside the window iff 32 n1 + c < lim
+        if constexpr (DSP_MASK_RECOMPUTE && NR == 16) { asm volatile("" : "+v"(lim)); }
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
             if (n1 < NR) {
@@ -434,9 +436,8 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
                     v = C{t.x, t.y};
                 }
                 if (NR == 16 || n1 == NR - 1) {          // rows that may reach past the window
-                    const int l = 32 * n1 + 2 * j;
-                    v.x = (l < L) ? v.x : T(0);
-                    v.y = (l + 1 < L) ? v.y : T(0);
+                    v.x = (32 * n1 < lim) ? v.x : T(0);
+                    v.y = (32 * n1 + 1 < lim) ? v.y : T(0);
                 }
                 C h;
                 if (WINREG) { h = hw[n1]; }
@@ -457,8 +458,7 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
 #pragma unroll
             for (int n1 = 0; n1 < NR; ++n1) {
                 if (NR == 16 || n1 == NR - 1) {          // rows that may reach past the window
-                    const int l = 32 * n1 + 2 * j;
-                    zz[n1] -= C{(l < L) ? mean : T(0), (l + 1 < L) ? mean : T(0)};
+                    zz[n1] -= C{(32 * n1 < lim) ? mean : T(0), (32 * n1 + 1 < lim) ? mean : T(0)};
                 } else {
                     zz[n1] -= C{mean, mean};
                 }

@@ -303,6 +303,8 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
         C zz[16];
         {
             C A[16];                                       // A[Q i + q]
+            [[maybe_unused]] int lim = L - 2 * j - 32 * g;  // element c of the pair (i, q) is inside the window iff 32 Q i + 512 q + c < lim
+            if constexpr (DSP_MASK_RECOMPUTE && !FULL) { asm volatile("" : "+v"(lim)); }
 #pragma unroll
             for (int i = 0; i < R; ++i) {
 #pragma unroll
@@ -312,9 +314,8 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
                     if constexpr (ALN) { const pair_a t = *reinterpret_cast<const pair_a *>(p); v = C{t.x, t.y}; }
                     else { const pair_u t = *reinterpret_cast<const pair_u *>(p); v = C{t.x, t.y}; }
                     if (!FULL) {                           // keep data past the window out (0 * NaN)
-                        const int l = 2 * j + 32 * (Q * i + g) + 512 * q;
-                        v.x = (l < L) ? v.x : T(0);
-                        v.y = (l + 1 < L) ? v.y : T(0);
+                        v.x = (32 * Q * i + 512 * q < lim) ? v.x : T(0);
+                        v.y = (32 * Q * i + 512 * q + 1 < lim) ? v.y : T(0);
                     }
                     A[Q * i + q] = v * hw[Q * i + q];
                 }
@@ -331,8 +332,7 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
                 for (int i = 0; i < R; ++i) {
 #pragma unroll
                     for (int q = 0; q < Q; ++q) {
-                        const int l = 2 * j + 32 * (Q * i + g) + 512 * q;
-                        A[Q * i + q] -= C{(FULL || l < L) ? mean : T(0), (FULL || l + 1 < L) ? mean : T(0)};
+                        A[Q * i + q] -= C{(FULL || 32 * Q * i + 512 * q < lim) ? mean : T(0), (FULL || 32 * Q * i + 512 * q + 1 < lim) ? mean : T(0)};
                     }
                 }
             }

@@ -4,6 +4,14 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
+#ifndef DSP_MASK_RECOMPUTE
+#define DSP_MASK_RECOMPUTE 0    // The lane masks of the rows that may reach past the window.  0: the compiler hoists the 32 masks out of
+                                // the step loop into scalar registers, which do not hold them all: they spill into the lanes of a vector
+                                // register and a select then costs two v_readlane and an s_nop.  1: they are recomputed every step from
+                                // one pinned register (a compare per select) -- measured 5 % SLOWER on the 512-point kernel (L 512 / hop
+                                // 128: 0.387 -> 0.409 ms) and the same on the 1024 / 2048-point one, so it stays off
+#endif
+
 namespace dsp {
 
 // One 16-byte-per-lane LDS-DMA load (1 KiB per wave: lane i's 16 bytes land at lds + 16 i).  Written in

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything the round-3 documents quote, in one call on the GPU box (outputs under gpurun_out/):
+# Everything the latest files under profiles/ come from, in one call on the GPU box (outputs under gpurun_out/):
 # bash tools/experiments/r03_final.sh
 set -o pipefail
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out

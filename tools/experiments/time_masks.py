@@ -1,0 +1,19 @@
+"""Shapes whose instantiations carry per-row lane masks (windows shorter than nfft, and the general-window instantiation of the
+512-point kernel, which also serves L = 512): kernel time and % of the HBM peak."""
+import sys
+sys.path.insert(0, '.')
+import numpy as np, torch, dsp_amd
+for (nfft, L, hop) in [(512, 512, 128), (512, 512, 256), (512, 300, 100), (1024, 800, 200), (2048, 1500, 512), (256, 256, 64), (128, 128, 32)]:
+    B, N = 8, 1 << 24
+    x = torch.randn((B, N), device='cuda') * 0.1
+    win = torch.from_numpy(dsp_amd.hann(L, np.float32)).cuda()
+    y = dsp_amd.stft_dev(x, win, hop, nfft=nfft)
+    for _ in range(30): dsp_amd.stft_dev(x, win, hop, nfft=nfft, out=y)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(30): dsp_amd.stft_dev(x, win, hop, nfft=nfft, out=y)
+    b.record(); torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / 30
+    print(f'nfft {nfft} L {L} hop {hop}: {ms:.4f} ms  {B * y.shape[1] * (hop + nfft // 2 + 1) * 4 / ms / 8e9 * 100:.1f} %', flush=True)
+    del x, y

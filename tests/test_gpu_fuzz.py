@@ -98,15 +98,15 @@ def test_random_shapes_stft_flt(O, D, dt):
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 def test_random_large_shapes_fast_kernels_against_generic(O, D, dt):
     """The kernels with work distribution over the whole chip (drawn steps, ranges per XCD, span slots refilled step after
-    step) on inputs of many steps per wave: random batches of long signals, transform lengths 64 to 4096, window lengths,
+    step) on inputs of many steps per wave: random batches of long signals, transform lengths 64 to 8192, window lengths,
     hops inside and outside the span limits, flags, snipped edges; against the generic kernels (one workgroup per frame,
     checked against the oracle by the tests above) on the same input, to the oracle's bound."""
     import torch
     rng = np.random.default_rng(4242 + np.dtype(dt).itemsize + 1000 * SEED)
     tdt = torch.float32 if dt == np.float32 else torch.float64
     g = torch.Generator(device="cuda").manual_seed(99 + SEED)
-    for it in range(40 * SCALE):
-        nfft = int(2 ** rng.integers(6, 13))
+    for it in range(48 * SCALE):
+        nfft = int(2 ** rng.integers(6, 14))
         L = int(rng.integers(nfft // 2, nfft + 1)) if rng.random() < 0.5 else nfft
         stp = int(rng.choice([nfft // 4, nfft // 2, nfft // 8 + 1, int(rng.integers(1, nfft + 2)), L]))
         stp = max(stp, nfft // 64)

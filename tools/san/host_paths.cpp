@@ -26,11 +26,13 @@ template <> struct Api<float> {
     static constexpr auto stft = stft_s; static constexpr auto stft_flt = stft_flt_s; static constexpr auto batch = dsp_stft_batch_s;
     static constexpr auto flt_batch = dsp_stft_flt_batch_s; static constexpr auto multi = dsp_stft_multi_s; static constexpr auto flt_multi = dsp_stft_flt_multi_s;
     static constexpr auto hann = hann_s; static constexpr auto pc = dsp_stft_pc_batch_s;
+    static constexpr auto strided = dsp_stft_batch_strided_s; static constexpr auto flt_strided = dsp_stft_flt_batch_strided_s;
 };
 template <> struct Api<double> {
     static constexpr auto stft = stft_d; static constexpr auto stft_flt = stft_flt_d; static constexpr auto batch = dsp_stft_batch_d;
     static constexpr auto flt_batch = dsp_stft_flt_batch_d; static constexpr auto multi = dsp_stft_multi_d; static constexpr auto flt_multi = dsp_stft_flt_multi_d;
     static constexpr auto hann = hann_d; static constexpr auto pc = dsp_stft_pc_batch_d;
+    static constexpr auto strided = dsp_stft_batch_strided_d; static constexpr auto flt_strided = dsp_stft_flt_batch_strided_d;
 };
 
 template <typename T> static void run(const char *name)
@@ -74,6 +76,29 @@ template <typename T> static void run(const char *name)
         CHECK(A::multi(y.data(), x.data(), win.data(), B, N, ldx, L, nfft, stp, 0, 0, 0, 0, devs, 1) == 0);
         CHECK(A::flt_multi(z.data(), x.data(), win.data(), B, N, ldx, L, Wf, nfft, (T)200, (T)160, 0, 0, 0, devs, 1) == 0);
     }
+    // interleaved channels ([N][C]) through the strided host forms: 8 channels (float32: read in place by the kernel), 6 channels
+    // (gathered), a block of 4 channels of the 8; against single calls on the channels copied out
+    {
+        const size_t N = 30000, W = frames(N, L, stp, 0);
+        for (size_t C : {size_t(8), size_t(6)}) {
+            std::vector<T> xi(N * C), ch(N), y(C * W * F), y1(W * F);
+            fill(xi, 4);
+            CHECK(A::strided(y.data(), xi.data(), win.data(), C, N, 1, C, L, nfft, stp, 0, 0, 0, 0) == 0);
+            for (size_t c : {size_t(0), C - 1}) {
+                for (size_t n = 0; n < N; ++n) { ch[n] = xi[n * C + c]; }
+                CHECK(A::stft(y1.data(), ch.data(), win.data(), N, L, nfft, stp, 0, 0, 0, 0) == 0);
+                double worst = 0, top = 0;
+                for (size_t i = 0; i < W * F; ++i) { worst = std::max(worst, std::fabs((double)y1[i] - (double)y[c * W * F + i])); top = std::max(top, (double)y1[i]); }
+                CHECK(worst <= 1e-5 * top);
+            }
+            if (C == 8) {
+                std::vector<T> yb(4 * W * F);
+                CHECK(A::strided(yb.data(), xi.data() + 4, win.data(), 4, N, 1, C, L, nfft, stp, 0, 1, 0, 1) == 0);
+                CHECK(A::flt_strided(yb.data(), xi.data(), win.data(), 4, N, 1, C, L, 150, nfft, (T)200, (T)160, 0, 0, 0) == 0);
+            }
+            CHECK(A::strided(y.data(), xi.data(), win.data(), C, N, 1, 0, L, nfft, stp, 0, 0, 0, 0) != 0);   // incx 0
+        }
+    }
     // one long signal streamed by ranges of frames; the head of it must equal a small call on its first samples
     {
         const size_t N = 20000003, W = frames(N, L, stp, 0), Nh = 50000, Wh = 200;
@@ -95,7 +120,7 @@ template <typename T> static void run(const char *name)
         }
         CHECK(dsp_stft_release_buffers() == 0);
         // other transform lengths through the same path
-        for (size_t n2 : {size_t(256), size_t(1024), size_t(4096), size_t(100)}) {
+        for (size_t n2 : {size_t(256), size_t(1024), size_t(4096), size_t(8192), size_t(100)}) {
             std::vector<T> w2(n2);
             CHECK(A::hann(w2.data(), n2, 0) == 0);
             const size_t N2 = n2 == 100 ? 2000000 : N, W2 = frames(N2, n2, n2 / 4, 0);

@@ -108,6 +108,12 @@ typedef unsigned u2v __attribute__((ext_vector_type(2)));
 #ifndef R4096_WREG_F64
 #define R4096_WREG_F64 1        // 1: the plain run form keeps the window in registers in float64 as well (128 of the wave's 512)
 #endif
+#ifndef R4096_TW_FULL
+#define R4096_TW_FULL 0         // 1: the plain float32 run form (window in registers, so 16 KB of LDS are free) reads the factor W2048^(n2 k1) of
+                                // every row from a table in LDS: 31 products per frame instead of the 52 of the two-factor form; 2: the
+                                // same with the reads of a group of four issued a group ahead.  Measured: 3.721 / 3.722 ms against 3.728 ms
+                                // (42 fewer packed instructions per frame for 0.2 %: the arithmetic is no longer what bounds the kernel)
+#endif
 #ifndef R4096_HACK
 #define R4096_HACK 0          // timing experiments only (wrong results): bit 1 = twiddle stage without the second factor, bit 3 = rows at a pitch of 2048 values (every store instruction on a 256-byte boundary)
 #endif
@@ -133,7 +139,8 @@ constexpr int R4096_X2P = 17;                           // second exchange: comp
 // which instantiations keep the window in registers instead of LDS: the run form without mean removal, epilogue or
 // complex rows (those need the registers themselves)
 constexpr bool r4096_wreg(bool mn0, bool epi, bool run, bool cplx) { return run && !mn0 && !epi && !cplx; }
-constexpr size_t r4096_lds(size_t elem, int waves, bool wtab, bool run) { return 2 * elem * ((size_t)waves * R4096_WAVE_C + (run ? 64 * 8 : 0)) + (wtab ? 4096 * elem : 0); }
+constexpr bool r4096_twfull(size_t elem, bool wreg) { return R4096_TW_FULL && wreg && elem == 4; }
+constexpr size_t r4096_lds(size_t elem, int waves, bool wtab, bool run, bool twfull) { return 2 * elem * ((size_t)waves * R4096_WAVE_C + (twfull ? 64 * 32 : run ? 64 * 8 : 0)) + (wtab ? 4096 * elem : 0); }
 
 // |a|^2 as a plain multiply and a plain fma: 2 + 2 issue cycles, where the packed square and the add of its halves take 4 + 2
 __device__ __forceinline__ float norm2(const cxf a) { return fmaf(a.y, a.y, a.x * a.x); }
@@ -181,6 +188,7 @@ __global__ __launch_bounds__(64 * r4096_waves<T>(), r4096_waves<T>() / 4) void s
     // (32 KB that the L2 keeps) frame by frame.
     constexpr bool WREG = r4096_wreg(MN0, EPI, RUN, CPLX) && (sizeof(T) == 4 || R4096_WREG_F64);
     constexpr bool WTAB = !WREG && sizeof(T) == 4;
+    constexpr bool TWFULL = r4096_twfull(sizeof(T), WREG);
     T *wtab = reinterpret_cast<T *>(smem_raw);
     C2 *tiles = reinterpret_cast<C2 *>(smem_raw) + (WTAB ? 2048 : 0);
     C2 *ex = tiles + wv * R4096_WAVE_C;                                               // this wave's tile
@@ -214,7 +222,10 @@ __global__ __launch_bounds__(64 * r4096_waves<T>(), r4096_waves<T>() / 4) void s
     // RUN keeps a frame's raw samples (and, WREG, the window) in registers; the twiddles that depend on the lane alone and
     // are used once per frame (ta) then live in LDS, behind the tiles, and are read ahead of their use
     C2 *twl = tiles + R4096_WAVES * R4096_WAVE_C;                             // ta[q] at [64 q + lane]
-    if (RUN && wv == 0) {
+    if constexpr (TWFULL) {
+        // ... or, where the LDS has room, the whole factor of every row: W2048^(n2 k1) at [64 k1 + lane]
+        for (int k1 = 1 + wv; k1 < 32; k1 += R4096_WAVES) { twl[64 * k1 + lane] = tw2048(n2 * k1); }
+    } else if (RUN && wv == 0) {
 #pragma unroll
         for (int q = 1; q < 8; ++q) { twl[64 * q + lane] = ta[q]; }
     }
@@ -467,12 +478,41 @@ __global__ __launch_bounds__(64 * r4096_waves<T>(), r4096_waves<T>() / 4) void s
         // twiddle W2048^(n2 k1), k1 = 4 q + b
 #if R4096_INTERLEAVE
         // four rows at a time, the products of a group before the fmas that consume them
+        [[maybe_unused]] C2 wnext[4];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             C2 *zp[4];
 #pragma unroll
             for (int bb = 0; bb < 4; ++bb) { const int k1 = 4 * q + bb; zp[bb] = (k1 < 16) ? &ze[slot16(k1)] : &zo[slot16(k1 - 16)]; }
             C2 t[4];
+            if constexpr (TWFULL) {
+                // the factors of group q + 1 are asked for before the products of group q are formed
+#if R4096_TW_FULL == 2
+                if (q == 0) {
+#pragma unroll
+                    for (int bb = 1; bb < 4; ++bb) { wnext[bb] = twl[64 * bb + lane]; }
+                }
+                C2 wq[4];
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) { wq[bb] = wnext[bb]; }
+                if (q < 7) {
+#pragma unroll
+                    for (int bb = 0; bb < 4; ++bb) { wnext[bb] = twl[64 * (4 * q + 4 + bb) + lane]; }
+                }
+#else
+                C2 wq[4];
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) { if (4 * q + bb) { wq[bb] = twl[64 * (4 * q + bb) + lane]; } }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) { if (4 * q + bb) { t[bb] = cx_mul_first<T>(*zp[bb], wq[bb]); } }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) { if (4 * q + bb) { *zp[bb] = cx_mul_second<T>(*zp[bb], wq[bb], t[bb]); } }
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+            }
 #pragma unroll
             for (int bb = 1; bb < 4; ++bb) { t[bb] = cx_mul_first<T>(*zp[bb], tb[bb]); }
             __builtin_amdgcn_sched_barrier(0);
@@ -748,7 +788,7 @@ template <typename T, bool FULL, bool MN0, bool EPI, bool RUN, bool CPLX = false
 static hipError_t launch_r4096_inst(T *Y, const T *X, const T *win, const T *tw, const R4096Args &a, hipStream_t s, unsigned *take)
 {
     constexpr int WAVES = r4096_waves<T>();
-    const size_t lds = r4096_lds(sizeof(T), WAVES, sizeof(T) == 4 && !r4096_wreg(MN0, EPI, RUN, CPLX), RUN);
+    const size_t lds = r4096_lds(sizeof(T), WAVES, sizeof(T) == 4 && !r4096_wreg(MN0, EPI, RUN, CPLX), RUN, r4096_twfull(sizeof(T), r4096_wreg(MN0, EPI, RUN, CPLX)));
     const auto kernel = &stft_r4096_kernel<T, FULL, MN0, EPI, RUN, CPLX>;
     static LdsGrant grant;
     if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(kernel), lds, grant); e != hipSuccess) { return e; }

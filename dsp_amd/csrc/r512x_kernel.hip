@@ -57,6 +57,10 @@ template <typename T> __host__ __device__ constexpr int r512x_waves() { return s
 #ifndef R512X_TWD_AHEAD
 #define R512X_TWD_AHEAD 1       // 1: the LDS twiddles of a step are read in one go before the pass-1 transform
 #endif
+#ifndef R512X_LOAD_SPREAD
+#define R512X_LOAD_SPREAD 0     // where the LDS-DMA loads of the next span are issued: 0 all behind pass 1's transform, 1 one after every second
+                                // exchange write, 2 all behind the exchange writes, 3 all behind pass 2's transform, 4 one per pair of the split (power form)
+#endif
 #ifndef R512X_NOLOAD
 #define R512X_NOLOAD 0          // diagnostic builds: 1 = the span loads fetch the twiddle table instead (no HBM reads)
 #endif
@@ -253,6 +257,17 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
                            });
     };
 
+    // ... and the same one load at a time (R512X_LOAD_SPREAD: where in the step the loads of the next span are issued)
+    auto span_fetch = [&](const T *sig, const int first, const int i) {
+        FrameDesc d{};
+        d.N = a.N; d.edge = a.edge;
+        return fetch_sample(sig, d, (long long)first, (long long)a.rd_shift, i);
+    };
+    RingSpan<T> nspan{};
+    auto span_piece = [&](const int q) __attribute__((always_inline)) {
+        if (q < NV) { ring_span_piece<T>(nspan, q, slot, reinterpret_cast<T *>(dummy), tw, need, lane, span_fetch); }
+    };
+
     // Work distribution: 8 contiguous ranges of steps, one per group of workgroups that share an XCD; a round
     // of a range is 8 neighbouring steps per workgroup, drawn by its waves from the counter.
     const int xcd = blockIdx.x & 7, nwg_x = gridDim.x >> 3;
@@ -384,7 +399,8 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
         // assembly statements): ring_drawn waits for every LDS operation of the wave.  Past the end of the
         // workgroup's share the current span is fetched again: the number of loads per step stays fixed.
         advance();
-        load_span(more ? nxb : xb, step_start(more ? nw : w));
+        if constexpr (R512X_LOAD_SPREAD == 0) { load_span(more ? nxb : xb, step_start(more ? nw : w)); }
+        else { nspan = ring_span_open<T>(more ? nxb : xb, step_start(more ? nw : w), need, a.N, a.edge, a.rd_shift); }
         R512X_STAMP(2);                                    // pass-1 transform, draw, span fetch issued
         {
             pair_a *exf = ex + grp * R512_EXF + j;
@@ -397,9 +413,14 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
                     else { v = cx_mul<T>(v, twd[k1]); }
                 }
                 exf[k1 * 17] = pair_a{v.x, v.y};
+                if constexpr (R512X_LOAD_SPREAD == 1) { if ((k1 & 1) == 0) { span_piece(k1 >> 1); } }
             }
         }
         wave_sync();
+        if constexpr (R512X_LOAD_SPREAD == 2) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) { span_piece(q); }
+        }
         R512X_STAMP(3);                                    // exchange writes
 
         // ---- pass 2: lane (group, k1 = j): 16-point FFT over the columns ----
@@ -409,6 +430,10 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
             for (int n2 = 0; n2 < 16; ++n2) { const pair_a t = exf[n2]; zz[n2] = C{t.x, t.y}; }
         }
         dft16x<T, 16>(zz);
+        if constexpr (R512X_LOAD_SPREAD == 3) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) { span_piece(q); }
+        }
 
         // ---- real-FFT split fused with power.  The lane holds Z[K] (halved), K = Q (j + 16 k2) + r, in
         // register k2.  Z[M - K] is, for r = 0: register 15 - k2 of lane (16 - j) % 16 (register (16 - k2) % 16
@@ -465,6 +490,7 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
             T pmid = T(4) * cx_norm<T>(zz[slot16(8)]);         // K = M / 2: lane j == 0 of group 0 only
 #pragma unroll
             for (int k2 = 0; k2 < 8; ++k2) {
+                if constexpr (R512X_LOAD_SPREAD == 4) { span_piece(k2); }
                 const C z = zz[slot16(k2)];
                 // (lane 0 of residue 0 is its own partner: the moves hand it its own register 15 - k2, which the last
                 // select replaces by register (16 - k2) % 16)

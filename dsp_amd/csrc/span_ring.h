@@ -123,4 +123,37 @@ __device__ __forceinline__ void ring_load_span(T *slot, T *dummy, const T *tw, c
     }
 }
 
+// The same span one load at a time, for kernels that place the NV loads between other work (what an LDS-DMA load costs the
+// wave that issues it depends on what else the wave is doing: back to back behind a transform they measured 160 cycles each).
+template <typename T> struct RingSpan { const T *src, *xb; int s0, nvec; bool inside; };
+template <typename T>
+__device__ __forceinline__ RingSpan<T> ring_span_open(const T *xb, const int s0, const int need, const int N, const int edge, const int rd_shift)
+{
+    constexpr int VEC = 16 / (int)sizeof(T);
+    RingSpan<T> r;
+    r.xb = xb; r.s0 = s0;
+    r.nvec = (need + VEC - 1) / VEC;
+    r.src = xb + (s0 - (edge ? rd_shift : 0));
+    r.inside = s0 >= 0 && s0 + VEC * r.nvec <= N && (edge == 0 || s0 >= rd_shift);
+    return r;
+}
+template <typename T, typename FETCH>
+__device__ __forceinline__ void ring_span_piece(const RingSpan<T> &r, const int q, T *slot, T *dummy, const T *tw, const int need, const int lane, FETCH fetch)
+{
+    constexpr int VEC = 16 / (int)sizeof(T);
+    typedef T vecT __attribute__((ext_vector_type(VEC)));
+    if (r.inside) {
+        ring_glds16(r.src + min(q * 64 + lane, r.nvec - 1) * VEC, __builtin_amdgcn_readfirstlane(ring_lds_addr(slot + q * 64 * VEC)));
+    } else {
+        vecT t;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const int i = (q * 64 + lane) * VEC + v;
+            t[v] = (i < need) ? fetch(r.xb, r.s0, i) : T(0);
+        }
+        reinterpret_cast<vecT *>(slot)[q * 64 + lane] = t;
+        ring_glds16(tw + lane * VEC, __builtin_amdgcn_readfirstlane(ring_lds_addr(dummy)));
+    }
+}
+
 }  // namespace dsp

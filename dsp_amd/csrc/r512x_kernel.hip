@@ -163,12 +163,25 @@ __device__ __forceinline__ void r512x_swap32(cx<double> &a, cx<double> &b) { r51
 // CPLX: the rows are the complex spectra (M + 1 interleaved (re, im) pairs per frame, the imaginary parts of the first and
 // last zero: window_univar followed by fft_fftw_r2hc, reference c/window_univar.c:41-89, c/fft.fftw.r2hc.c:69-78) instead of
 // their powers.
-template <typename T, int Q, bool FULL, bool MN0, bool EPI, int SPAN, bool ALN, bool CPLX = false>
+// RQ (nfft 2048, full window, hop 512 = a quarter of the frame): the slot is a ring of four quarters.  A wave draws UNITS of
+// R512X_UNIT consecutive frames of one signal instead of single steps; frame t of a unit is the quarters t .. t + 3 of the unit's
+// samples, quarter n lives at slot position n % 4, and once pass 1 of frame t has read the slot only quarter t + 4 is fetched, into
+// the position of quarter t (2 loads of 1 KiB per frame instead of 8; a unit's first frame takes all 8).  Issuing an LDS-DMA load
+// costs the wave about 160 cycles where these go out, and a 2048-point step spent 1.3 k of its 7.6 k cycles on them.  Same
+// arithmetic on the same samples as the step form: the two return the same bits.
+#ifndef R512X_UNIT_FRAMES
+#define R512X_UNIT_FRAMES 6       // measured on 64 x 60 s @ 44.1 kHz, float32 / float64 ms: 4: 0.537 / 1.196, 6: 0.532 / 1.181, 8: 0.541 / 1.188, 12: 0.537 / 1.180,
+                                 // 16: 0.545, 32: 0.557, 64: 0.583 (single steps: 0.562 / 1.329): longer units spread the rows a workgroup writes
+#endif
+constexpr int R512X_UNIT = R512X_UNIT_FRAMES;
+template <typename T, int Q, bool FULL, bool MN0, bool EPI, int SPAN, bool ALN, bool CPLX = false, bool RQ = false>
 __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void stft_r512x_kernel(T *__restrict__ Y, const T *__restrict__ X,
                                                                                                const T *__restrict__ win, const T *__restrict__ tw,
                                                                                                const R512XArgs a)
 {
     static_assert(Q == 2 || Q == 4, "nfft 1024 or 2048");
+    static_assert(!RQ || (Q == 4 && FULL && SPAN == 2048 && ALN), "the ring of quarters: nfft 2048, full window");
+    constexpr int FPU = RQ ? R512X_UNIT : 4 / Q;           // frames per drawn unit of work
     using C = cx<T>;
     typedef T pair_u __attribute__((ext_vector_type(2), aligned(sizeof(T))));        // a pair of samples at sample alignment
     typedef T pair_a __attribute__((ext_vector_type(2), aligned(2 * sizeof(T))));    // ... at its own alignment
@@ -276,7 +289,8 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
     int sid = first + wv;
     if (sid >= s_hi) { return; }
     int b = sid / a.sps;
-    int w = (sid - b * a.sps) * FPS;
+    int w = (sid - b * a.sps) * FPU;
+    [[maybe_unused]] int t = 0, ulen = RQ ? min(FPU, a.W - w) : 1;      // RQ: the frame inside the unit, the unit's frames
     const T *xb = X + (long long)b * a.ldx;
     T *yb = Y + (long long)b * a.Wy * ROWF;
 
@@ -292,7 +306,7 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
         more = nsid < s_hi;
         if (more) {
             const int nb = nsid / a.sps;
-            nw = (nsid - nb * a.sps) * FPS;
+            nw = (nsid - nb * a.sps) * FPU;
             nxb = X + (long long)nb * a.ldx;
             nyb = Y + (long long)nb * a.Wy * ROWF;
         }
@@ -306,7 +320,8 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory");
 #endif
     while (true) {
-        ring_draw(drawn, cnt_addr);                       // the step after this one: asked for now, needed further down
+        // the step after this one: asked for now, needed further down (RQ: when this is the unit's last frame)
+        if (!RQ || t + 1 >= ulen) { ring_draw(drawn, cnt_addr); }
         // The span of this step was asked for in the middle of the last one; memory operations complete in issue
         // order and behind its NV loads lie that step's 5 row stores, which stay in flight.
         if (first_step) { ring_wait_vm<0>(); } else { ring_wait_vm<NSTORE>(); }
@@ -324,7 +339,7 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
             for (int i = 0; i < R; ++i) {
 #pragma unroll
                 for (int q = 0; q < Q; ++q) {
-                    const T *p = xrow + 32 * Q * i + 512 * q;
+                    const T *p = xrow + 32 * Q * i + 512 * (RQ ? ((q + t) & 3) : q);
                     C v;
                     if constexpr (ALN) { const pair_a t = *reinterpret_cast<const pair_a *>(p); v = C{t.x, t.y}; }
                     else { const pair_u t = *reinterpret_cast<const pair_u *>(p); v = C{t.x, t.y}; }
@@ -398,9 +413,24 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
         // the slot is issued (the compiler may sink their consumers, and with them its own wait, below the
         // assembly statements): ring_drawn waits for every LDS operation of the wave.  Past the end of the
         // workgroup's share the current span is fetched again: the number of loads per step stays fixed.
-        advance();
-        if constexpr (R512X_LOAD_SPREAD == 0) { load_span(more ? nxb : xb, step_start(more ? nw : w)); }
-        else { nspan = ring_span_open<T>(more ? nxb : xb, step_start(more ? nw : w), need, a.N, a.edge, a.rd_shift); }
+        [[maybe_unused]] bool same_unit = false;
+        if constexpr (RQ) {
+            same_unit = t + 1 < ulen;
+            if (same_unit) {
+                // the next frame of the unit: its last quarter into the position of this frame's first
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                more = true;
+                ring_load_span<NV / 4>(slot + 512 * (t & 3), reinterpret_cast<T *>(dummy), tw, xb, a.ss0 + (w + 1) * a.stp + 1536, 512, a.N, a.edge, a.rd_shift, lane,
+                                       span_fetch);
+            } else {
+                advance();
+                load_span(more ? nxb : xb, step_start(more ? nw : w));
+            }
+        } else {
+            advance();
+            if constexpr (R512X_LOAD_SPREAD == 0) { load_span(more ? nxb : xb, step_start(more ? nw : w)); }
+            else { nspan = ring_span_open<T>(more ? nxb : xb, step_start(more ? nw : w), need, a.N, a.edge, a.rd_shift); }
+        }
         R512X_STAMP(2);                                    // pass-1 transform, draw, span fetch issued
         {
             pair_a *exf = ex + grp * R512_EXF + j;
@@ -549,7 +579,11 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
         R512X_STAMP(7);                                    // stores issued
         if (!more) { break; }
         wave_sync();                                       // staging reads are done before the next step writes the tile
-        sid = nsid; w = nw; xb = nxb; yb = nyb;
+        if (RQ && same_unit) { ++t; ++w; }
+        else {
+            sid = nsid; w = nw; xb = nxb; yb = nyb;
+            if constexpr (RQ) { t = 0; ulen = min(FPU, a.W - w); }
+        }
     }
     // no LDS-DMA load may land, and no draw return, after the wave has ended
     ring_wait_vm<0>();
@@ -582,18 +616,45 @@ bool r512x_supported(const FrameDesc &d)
            d.ss0 > -(1ll << 30) && d.ss0 < (1ll << 30) && d.rd_shift >= 0 && d.rd_shift < (1ll << 30);
 }
 
-template <typename T, int Q, bool FULL, bool MN0, bool EPI, int SPAN, bool ALN, bool CPLX = false>
+template <typename T, int Q, bool FULL, bool MN0, bool EPI, int SPAN, bool ALN, bool CPLX = false, bool RQ = false>
 static hipError_t launch_r512x_inst(T *Y, const T *X, const T *win, const T *tw, const R512XArgs &a, hipStream_t s)
 {
     constexpr int NWV = r512x_waves<T>();
     const size_t lds = ((size_t)NWV * (R512X_TILE + SPAN) + (R512X_TWD_LDS ? 512 : 0)) * sizeof(T) + 1024 + 16;
     static LdsGrant grant;
-    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r512x_kernel<T, Q, FULL, MN0, EPI, SPAN, ALN, CPLX>), lds, grant); e != hipSuccess) { return e; }
+    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r512x_kernel<T, Q, FULL, MN0, EPI, SPAN, ALN, CPLX, RQ>), lds, grant); e != hipSuccess) { return e; }
     long long grid = ((long long)a.steps + NWV - 1) / NWV;
     if (grid > 256) { grid = 256; }                     // one workgroup per CU
     grid = (grid + 7) & ~7ll;                           // whole groups of 8 workgroups (one per XCD)
-    hipLaunchKernelGGL((stft_r512x_kernel<T, Q, FULL, MN0, EPI, SPAN, ALN, CPLX>), dim3((unsigned)grid), dim3(64 * NWV), lds, s, Y, X, win, tw, a);
+    hipLaunchKernelGGL((stft_r512x_kernel<T, Q, FULL, MN0, EPI, SPAN, ALN, CPLX, RQ>), dim3((unsigned)grid), dim3(64 * NWV), lds, s, Y, X, win, tw, a);
     return hipGetLastError();
+}
+
+// Whether a launch takes the ring-of-quarters form: nfft 2048, full window, frames at ss0 + 512 w, and enough units of
+// R512X_UNIT frames: at least DSP_R512X_MIN_UNITS (default: two per wave of a full grid; 0 = never)
+template <typename T>
+static bool r512x_ring(const FrameDesc &d)
+{
+#if R512X_MINIMAL
+    return false;
+#else
+    long long min_units = 2 * 256 * r512x_waves<T>();
+    if (const char *e = getenv("DSP_R512X_MIN_UNITS")) { min_units = atoll(e) > 0 ? atoll(e) : (1ll << 62); }
+    const long long units = (long long)d.B * ((d.W + R512X_UNIT - 1) / R512X_UNIT);
+    return d.nfft == 2048 && d.L == 2048 && d.tbl == nullptr && d.stp == 512 && units >= min_units;
+#endif
+}
+
+template <typename T>
+static hipError_t launch_r512x_ring(T *Y, const T *X, const T *win, const T *tw, R512XArgs a, const FrameDesc &d, hipStream_t s)
+{
+    a.sps = (d.W + R512X_UNIT - 1) / R512X_UNIT;          // units per signal
+    a.steps = d.B * a.sps;
+    const bool epi = d.epi.any();
+#define DSP_R512Q(M_, E_) launch_r512x_inst<T, 4, true, M_, E_, 2048, true, false, true>(Y, X, win, tw, a, s)
+    if (d.mn0) { return epi ? DSP_R512Q(true, true) : DSP_R512Q(true, false); }
+    return epi ? DSP_R512Q(false, true) : DSP_R512Q(false, false);
+#undef DSP_R512Q
 }
 
 template <typename T, int Q, int SPAN, bool ALN>
@@ -626,6 +687,7 @@ static hipError_t launch_r512x_any(T *Y, const T *X, const T *win, const T *tw, 
     a.steps = d.B * a.sps;
     a.tbl = d.tbl; a.reach = 0;
     if (d.tbl) { a.stp = 0; a.ss0 = 0; a.rd_shift = 0; a.reach = (fps == 1) ? 0 : d.tbl_reach; }
+    if (Q == 4 && r512x_ring<T>(d)) { return launch_r512x_ring<T>(Y, X, win, tw, a, d, s); }
     if (Q == 4) { return launch_r512x_shape<T, 4, 2048, true>(Y, X, win, tw, a, d, s); }
     if (d.tbl || (d.stp & 1)) { return launch_r512x_shape<T, 2, 2048, false>(Y, X, win, tw, a, d, s); }
     if (d.stp + 1024 <= 1280) { return launch_r512x_shape<T, 2, 1280, true>(Y, X, win, tw, a, d, s); }
@@ -668,6 +730,11 @@ static hipError_t launch_r512x_cplx_any(T *Y, const T *X, const T *win, const T 
     a.steps = d.B * a.sps;
     a.tbl = nullptr; a.reach = 0;
     a.cscale = scale;
+    if (Q == 4 && r512x_ring<T>(d)) {
+        a.sps = (d.W + R512X_UNIT - 1) / R512X_UNIT;
+        a.steps = d.B * a.sps;
+        return launch_r512x_inst<T, 4, true, false, false, 2048, true, true, true>(Y, X, win, tw, a, s);
+    }
     if (Q == 4) { return launch_r512x_cplx_shape<T, 4, 2048, true>(Y, X, win, tw, a, d, s); }
     if (d.stp & 1) { return launch_r512x_cplx_shape<T, 2, 2048, false>(Y, X, win, tw, a, d, s); }
     if (d.stp + 1024 <= 1280) { return launch_r512x_cplx_shape<T, 2, 1280, true>(Y, X, win, tw, a, d, s); }

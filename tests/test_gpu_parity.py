@@ -450,6 +450,59 @@ def test_both_4096_families_agree_with_oracle(O, D, dt):
             D.set_flt_mode(False)
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_2048_ring_of_quarters(O, D, dt, monkeypatch):
+    """nfft 2048 with a full window and hop 512: large inputs are transformed in units of consecutive frames per wave, the
+    span slot kept as a ring of four quarters of which only the new one is fetched per frame.  Forced here at small sizes
+    (DSP_R512X_MIN_UNITS=1): units that cross either edge of the signal, a last unit shorter than the others, signals
+    shorter than one unit and shorter than the window, several signals, every flag, both edge rules, the complex form;
+    against the oracle and, bit for bit, against the step form of the same kernel."""
+    import torch
+    win = D.hann(2048, dt)
+    wd = torch.from_numpy(win).cuda()
+    tdt = torch.float32 if dt == np.float32 else torch.float64
+    for (B, N, snip, flags) in [(3, 512 * 100 + 7, 0, (0, 0, 0)), (2, 512 * 37, 1, (1, 0, 0)), (1, 3000, 0, (0, 1, 1)), (5, 512 * 18 + 2048, 1, (0, 0, 0)),
+                                (2, 512 * 7 + 100, 0, (1, 1, 0)), (1, 1500, 0, (0, 0, 1)), (4, 512 * 6 * 9, 0, (1, 1, 1))]:
+        x = np.stack([signal(7 * b + N, N, dt) + dt(0.1) for b in range(B)])
+        xd = torch.from_numpy(x).cuda()
+        got = {}
+        for mu in ("1", "0"):
+            monkeypatch.setenv("DSP_R512X_MIN_UNITS", mu)
+            got[mu] = D.stft_dev(xd, wd, 512, bool(snip), *[bool(f) for f in flags], nfft=2048).cpu().numpy()
+        assert np.array_equal(got["1"], got["0"]), (B, N, snip, flags)
+        for b in (0, B - 1):
+            rc, Yref = O.stft(x[b].astype(np.float64), win.astype(np.float64), 512, 2048, snip, *flags, exact=False)
+            assert rc == 0
+            check_spec(O, got["1"][b], Yref.astype(dt), flags[1], flags[2])
+    # the complex form, and an output that is a view with other rows around it
+    x = np.stack([signal(31 + b, 512 * 50, dt) for b in range(2)])
+    xd = torch.from_numpy(x).cuda()
+    got = {}
+    for mu in ("1", "0"):
+        monkeypatch.setenv("DSP_R512X_MIN_UNITS", mu)
+        got[mu] = D.stft_cplx_dev(xd, wd, 512, nfft=2048, sc=True)
+    assert torch.equal(got["1"], got["0"])
+    monkeypatch.setenv("DSP_R512X_MIN_UNITS", "1")
+    want = D.stft_dev(xd, wd, 512, nfft=2048)
+    buf = torch.full((want.numel() + 6,), 7.0, dtype=tdt, device="cuda")
+    out = buf[3:3 + want.numel()].view(want.shape)
+    D.stft_dev(xd, wd, 512, nfft=2048, out=out)
+    torch.cuda.synchronize()
+    assert torch.equal(out, want) and bool((buf[:3] == 7.0).all()) and bool((buf[3 + want.numel():] == 7.0).all())
+    # stft_flt with an integral hop of 512 takes the same form (zero edges, read shift)
+    xs = signal(5, 40000, dt)
+    for intended in (False, True):
+        D.set_flt_mode(intended)
+        try:
+            for (c0, W) in [(0.0, 60), (1024.0, 70), (-3000.0, 50)]:
+                rc, Yref = O.stft_flt(xs.astype(np.float64), win.astype(np.float64), W, c0, 512.0, 2048, 0, 0, 0, intended=intended, exact=False)
+                assert rc == 0
+                Y = D.stft_flt(xs, win, W, c0, 512.0, nfft=2048)
+                check_spec(O, Y, Yref.astype(dt))
+        finally:
+            D.set_flt_mode(False)
+
+
 def test_8192_kernel_agrees_with_oracle(O, D):
     """nfft 8192 (float32) has a register-resident kernel (a 64 x 64 transform per wave, 4 waves per workgroup): full
     and short windows, odd hops (unaligned frame starts), a signal shorter than the window, every flag, a batch with

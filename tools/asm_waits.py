@@ -159,8 +159,12 @@ def check(lib):
                 low = [q for q in set(seqs) if q < min(waits)]
                 problems.append(f"store instructions per sequence {sorted(set(seqs))} != counted waits {sorted(set(waits))}" +
                                 (f" (UNSAFE: a sequence of {low} stores is shorter than every wait)" if low else ""))
-            if len(set(dmas)) != 1:
-                problems.append(f"LDS-DMA loads per sequence: {sorted(set(dmas))} (one fixed number expected)")
+            # (the number of loads does not enter a wait -- what the wait counts are the stores behind them -- but a kernel
+            # issues a fixed number per span: NV, or, in the ring-of-quarters form of the 2048-point kernel, NV for a unit's
+            # first frame and NV / 4 for the others)
+            d = sorted(set(dmas))
+            if not (len(d) == 1 or (len(d) == 2 and 4 * d[0] == d[1] and "stft_r512x_kernel" in name)):
+                problems.append(f"LDS-DMA loads per sequence: {d} (one fixed number expected, or NV / 4 and NV in the ring form)")
             rows.append((name, sorted(set(waits)), sorted(seqs), sorted(set(dmas)), "; ".join(problems) or None))
     return rows
 

@@ -452,7 +452,7 @@ def test_both_4096_families_agree_with_oracle(O, D, dt):
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 def test_2048_ring_of_quarters(O, D, dt, monkeypatch):
-    """nfft 2048 with a full window and hop 512: large inputs are transformed in units of consecutive frames per wave, the
+    """nfft 2048 with a full window and hop 512 or 1024: large inputs are transformed in units of consecutive frames per wave, the
     span slot kept as a ring of four quarters of which only the new one is fetched per frame.  Forced here at small sizes
     (DSP_R512X_MIN_UNITS=1): units that cross either edge of the signal, a last unit shorter than the others, signals
     shorter than one unit and shorter than the window, several signals, every flag, both edge rules, the complex form;
@@ -465,15 +465,16 @@ def test_2048_ring_of_quarters(O, D, dt, monkeypatch):
                                 (2, 512 * 7 + 100, 0, (1, 1, 0)), (1, 1500, 0, (0, 0, 1)), (4, 512 * 6 * 9, 0, (1, 1, 1))]:
         x = np.stack([signal(7 * b + N, N, dt) + dt(0.1) for b in range(B)])
         xd = torch.from_numpy(x).cuda()
-        got = {}
-        for mu in ("1", "0"):
-            monkeypatch.setenv("DSP_R512X_MIN_UNITS", mu)
-            got[mu] = D.stft_dev(xd, wd, 512, bool(snip), *[bool(f) for f in flags], nfft=2048).cpu().numpy()
-        assert np.array_equal(got["1"], got["0"]), (B, N, snip, flags)
-        for b in (0, B - 1):
-            rc, Yref = O.stft(x[b].astype(np.float64), win.astype(np.float64), 512, 2048, snip, *flags, exact=False)
-            assert rc == 0
-            check_spec(O, got["1"][b], Yref.astype(dt), flags[1], flags[2])
+        for hop in (512, 1024):
+            got = {}
+            for mu in ("1", "0"):
+                monkeypatch.setenv("DSP_R512X_MIN_UNITS", mu)
+                got[mu] = D.stft_dev(xd, wd, hop, bool(snip), *[bool(f) for f in flags], nfft=2048).cpu().numpy()
+            assert np.array_equal(got["1"], got["0"]), (B, N, snip, flags, hop)
+            for b in (0, B - 1):
+                rc, Yref = O.stft(x[b].astype(np.float64), win.astype(np.float64), hop, 2048, snip, *flags, exact=False)
+                assert rc == 0
+                check_spec(O, got["1"][b], Yref.astype(dt), flags[1], flags[2])
     # the complex form, and an output that is a view with other rows around it
     x = np.stack([signal(31 + b, 512 * 50, dt) for b in range(2)])
     xd = torch.from_numpy(x).cuda()

@@ -161,10 +161,10 @@ def check(lib):
                                 (f" (UNSAFE: a sequence of {low} stores is shorter than every wait)" if low else ""))
             # (the number of loads does not enter a wait -- what the wait counts are the stores behind them -- but a kernel
             # issues a fixed number per span: NV, or, in the ring-of-quarters form of the 2048-point kernel, NV for a unit's
-            # first frame and NV / 4 for the others)
+            # first frame and NV / 4 or NV / 2 (hop 512 or 1024) for the others)
             d = sorted(set(dmas))
-            if not (len(d) == 1 or (len(d) == 2 and 4 * d[0] == d[1] and "stft_r512x_kernel" in name)):
-                problems.append(f"LDS-DMA loads per sequence: {d} (one fixed number expected, or NV / 4 and NV in the ring form)")
+            if not (len(d) == 1 or ("stft_r512x_kernel" in name and all(v in (d[-1] // 4, d[-1] // 2, d[-1]) for v in d))):
+                problems.append(f"LDS-DMA loads per sequence: {d} (one fixed number expected, or NV / 4, NV / 2 and NV in the ring form)")
             rows.append((name, sorted(set(waits)), sorted(seqs), sorted(set(dmas)), "; ".join(problems) or None))
     return rows
 

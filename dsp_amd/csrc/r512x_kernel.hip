@@ -52,7 +52,7 @@ constexpr int R512X_TILE = 4 * R512_EXF * 2;          // floats of a wave's exch
 template <typename T> __host__ __device__ constexpr int r512x_waves() { return sizeof(T) == 4 ? 8 : 4; }   // per workgroup
 
 #ifndef R512X_TWD_LDS
-#define R512X_TWD_LDS (sizeof(T) == 4 && (Q == 4 || SPAN == 2048))   // where the pass-1 twiddles of the 256-point transform come from an LDS table instead of 30 registers (these instantiations spill otherwise; measured: 1024 / hop 512 0.480 -> 0.449 ms, and 6 % slower where nothing spills)
+#define R512X_TWD_LDS (sizeof(T) == 4 && (Q == 4 || (SPAN == 2048 && !RQ)))   // where the pass-1 twiddles of the 256-point transform come from an LDS table instead of 30 registers (these instantiations spill otherwise; measured: 1024 / hop 512 0.480 -> 0.449 ms, and 6 % slower where nothing spills)
 #endif
 #ifndef R512X_TWD_AHEAD
 #define R512X_TWD_AHEAD 1       // 1: the LDS twiddles of a step are read in one go before the pass-1 transform
@@ -173,15 +173,21 @@ __device__ __forceinline__ void r512x_swap32(cx<double> &a, cx<double> &b) { r51
 #define R512X_UNIT_FRAMES 6       // measured on 64 x 60 s @ 44.1 kHz, float32 / float64 ms: 4: 0.537 / 1.196, 6: 0.532 / 1.181, 8: 0.541 / 1.188, 12: 0.537 / 1.180,
                                  // 16: 0.545, 32: 0.557, 64: 0.583 (single steps: 0.562 / 1.329): longer units spread the rows a workgroup writes
 #endif
-constexpr int R512X_UNIT = R512X_UNIT_FRAMES;
+constexpr int R512X_UNIT = R512X_UNIT_FRAMES;   // steps per unit
+#ifndef R512X_RING_1024
+#define R512X_RING_1024 0       // 1: nfft 1024 with a full window and hop 256 takes the ring form as well (two frames per step, blocks t .. t + 2 of a
+                                // ring of four): same bits, but measured SLOWER than the 1280-sample span of the step form, 0.468 -> 0.481 ms in
+                                // float32 and 1.055 -> 1.08 ms in float64 (units of 4, 6 or 12 steps alike): the step form fetches 5 loads per step
+                                // there, the ring 3 on average, and pays for them with a per-lane choice of block and a slot of 2048 samples
+#endif
 template <typename T, int Q, bool FULL, bool MN0, bool EPI, int SPAN, bool ALN, bool CPLX = false, bool RQ = false>
 __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void stft_r512x_kernel(T *__restrict__ Y, const T *__restrict__ X,
                                                                                                const T *__restrict__ win, const T *__restrict__ tw,
                                                                                                const R512XArgs a)
 {
     static_assert(Q == 2 || Q == 4, "nfft 1024 or 2048");
-    static_assert(!RQ || (Q == 4 && FULL && SPAN == 2048 && ALN), "the ring of quarters: nfft 2048, full window");
-    constexpr int FPU = RQ ? R512X_UNIT : 4 / Q;           // frames per drawn unit of work
+    static_assert(!RQ || (FULL && SPAN == 2048 && ALN), "the ring form: full window, a 2048-sample slot");
+    constexpr int FPU = RQ ? R512X_UNIT * (4 / Q) : 4 / Q;   // frames per drawn unit of work (RQ: R512X_UNIT steps)
     using C = cx<T>;
     typedef T pair_u __attribute__((ext_vector_type(2), aligned(sizeof(T))));        // a pair of samples at sample alignment
     typedef T pair_a __attribute__((ext_vector_type(2), aligned(2 * sizeof(T))));    // ... at its own alignment
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
     __syncthreads();
 
     const int reach = a.tbl ? a.reach : (FPS - 1) * a.stp;
-    const int need = reach + L;                            // samples of a span that pass 1 uses
+    const int need = (RQ && Q == 2) ? 1536 : reach + L;    // samples of a span that pass 1 uses (RQ, nfft 1024: three whole blocks)
     const T *xrow = slot + f * a.stp + 2 * j + 32 * g;   // row i, quarter q at xrow[32 Q i + 512 q]
     // Start of the span of the step at frame w_ (wave-uniform).  Table form: the starts of the step's frames by
     // scalar loads (a vector load would put the compiler's own wait for ALL outstanding memory operations, the row
@@ -290,8 +296,9 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
     if (sid >= s_hi) { return; }
     int b = sid / a.sps;
     int w = (sid - b * a.sps) * FPU;
-    [[maybe_unused]] int t = 0, ulen = RQ ? min(FPU, a.W - w) : 1;      // RQ: the frame inside the unit, the unit's frames
-    [[maybe_unused]] const int qstep = RQ ? a.stp >> 9 : 0;             // RQ: quarters between two frames (hop 512: 1, hop 1024: 2)
+    [[maybe_unused]] int t = 0, ulen = RQ ? (min(FPU, a.W - w) + FPS - 1) / FPS : 1;      // RQ: the step inside the unit, the unit's steps
+    // RQ: 512-sample blocks between two steps (nfft 2048: hop 512: 1, hop 1024: 2; nfft 1024, two frames per step at hop 256: 1)
+    [[maybe_unused]] const int qstep = RQ ? (FPS * a.stp) >> 9 : 0;
     const T *xb = X + (long long)b * a.ldx;
     T *yb = Y + (long long)b * a.Wy * ROWF;
 
@@ -332,6 +339,16 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
 
         // ---- input stage: the group's rows in all Q quarters, windowed; Q-point butterflies; twiddles ----
         C zz[16];
+        // RQ, nfft 1024: step t of a unit is the blocks t, t + 1, t + 2 of the unit's samples, block n at ring position n % 4.  Half q of
+        // frame 0 is block q; frame 1 starts 256 samples further on, so its rows i >= 4 lie one block further (at 256 samples less).
+        [[maybe_unused]] const T *rq_lo[2] = {xrow, xrow}, *rq_hi[2] = {xrow, xrow};
+        if constexpr (RQ && Q == 2) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                rq_lo[q] = xrow + 512 * ((q + t) & 3);
+                rq_hi[q] = f ? xrow - 512 + 512 * ((q + 1 + t) & 3) : rq_lo[q];
+            }
+        }
         {
             C A[16];                                       // A[Q i + q]
             [[maybe_unused]] int lim = L - 2 * j - 32 * g;  // element c of the pair (i, q) is inside the window iff 32 Q i + 512 q + c < lim
@@ -340,7 +357,9 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
             for (int i = 0; i < R; ++i) {
 #pragma unroll
                 for (int q = 0; q < Q; ++q) {
-                    const T *p = xrow + 32 * Q * i + 512 * (RQ ? ((q + qstep * t) & 3) : q);
+                    const T *p;
+                    if constexpr (RQ && Q == 2) { p = (i < 4 ? rq_lo[q] : rq_hi[q]) + 32 * Q * i; }
+                    else { p = xrow + 32 * Q * i + 512 * (RQ ? ((q + qstep * t) & 3) : q); }
                     C v;
                     if constexpr (ALN) { const pair_a t = *reinterpret_cast<const pair_a *>(p); v = C{t.x, t.y}; }
                     else { const pair_u t = *reinterpret_cast<const pair_u *>(p); v = C{t.x, t.y}; }
@@ -422,8 +441,9 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 more = true;
                 // (hop 1024: its last two quarters, which lie side by side in the ring as well)
-                T *const pos = slot + 512 * ((qstep * t) & 3);
-                const int s_new = a.ss0 + (w + 1) * a.stp + (2048 - a.stp);
+                // (nfft 1024: block t + 3, which this step does not touch)
+                T *const pos = slot + 512 * ((Q == 2 ? t + 3 : qstep * t) & 3);
+                const int s_new = a.ss0 + (w + FPS) * a.stp + (Q == 2 ? 1024 : 2048 - a.stp);
                 if (qstep == 1) { ring_load_span<NV / 4>(pos, reinterpret_cast<T *>(dummy), tw, xb, s_new, 512, a.N, a.edge, a.rd_shift, lane, span_fetch); }
                 else { ring_load_span<NV / 2>(pos, reinterpret_cast<T *>(dummy), tw, xb, s_new, 1024, a.N, a.edge, a.rd_shift, lane, span_fetch); }
             } else {
@@ -583,10 +603,10 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
         R512X_STAMP(7);                                    // stores issued
         if (!more) { break; }
         wave_sync();                                       // staging reads are done before the next step writes the tile
-        if (RQ && same_unit) { ++t; ++w; }
+        if (RQ && same_unit) { ++t; w += FPS; }
         else {
             sid = nsid; w = nw; xb = nxb; yb = nyb;
-            if constexpr (RQ) { t = 0; ulen = min(FPU, a.W - w); }
+            if constexpr (RQ) { t = 0; ulen = (min(FPU, a.W - w) + FPS - 1) / FPS; }
         }
     }
     // no LDS-DMA load may land, and no draw return, after the wave has ended
@@ -642,21 +662,25 @@ static bool r512x_ring(const FrameDesc &d)
 #if R512X_MINIMAL
     return false;
 #else
+    const int fpu = R512X_UNIT * (d.nfft == 2048 ? 1 : 2);      // frames per unit
     long long min_units = 2 * 256 * r512x_waves<T>();
     if (const char *e = getenv("DSP_R512X_MIN_UNITS")) { min_units = atoll(e) > 0 ? atoll(e) : (1ll << 62); }
-    const long long units = (long long)d.B * ((d.W + R512X_UNIT - 1) / R512X_UNIT);
-    // (hop 1024 measured 4 % faster in float64, 0.2827 -> 0.2715 ms on 8 x 2^23 samples, and 1.5 % slower in float32: float64 only)
-    return d.nfft == 2048 && d.L == 2048 && d.tbl == nullptr && (d.stp == 512 || (d.stp == 1024 && sizeof(T) == 8)) && units >= min_units;
+    const long long units = (long long)d.B * ((d.W + fpu - 1) / fpu);
+    if (d.L != d.nfft || d.tbl != nullptr || units < min_units) { return false; }
+    // (nfft 2048, hop 1024 measured 4 % faster in float64, 0.2827 -> 0.2715 ms on 8 x 2^23 samples, and 1.5 % slower in float32: float64 only)
+    if (d.nfft == 2048) { return d.stp == 512 || (d.stp == 1024 && sizeof(T) == 8); }
+    return d.nfft == 1024 && d.stp == 256 && R512X_RING_1024;
 #endif
 }
 
-template <typename T>
+template <typename T, int Q>
 static hipError_t launch_r512x_ring(T *Y, const T *X, const T *win, const T *tw, R512XArgs a, const FrameDesc &d, hipStream_t s)
 {
-    a.sps = (d.W + R512X_UNIT - 1) / R512X_UNIT;          // units per signal
+    constexpr int fpu = R512X_UNIT * (4 / Q);
+    a.sps = (d.W + fpu - 1) / fpu;                          // units per signal
     a.steps = d.B * a.sps;
     const bool epi = d.epi.any();
-#define DSP_R512Q(M_, E_) launch_r512x_inst<T, 4, true, M_, E_, 2048, true, false, true>(Y, X, win, tw, a, s)
+#define DSP_R512Q(M_, E_) launch_r512x_inst<T, Q, true, M_, E_, 2048, true, false, true>(Y, X, win, tw, a, s)
     if (d.mn0) { return epi ? DSP_R512Q(true, true) : DSP_R512Q(true, false); }
     return epi ? DSP_R512Q(false, true) : DSP_R512Q(false, false);
 #undef DSP_R512Q
@@ -692,7 +716,12 @@ static hipError_t launch_r512x_any(T *Y, const T *X, const T *win, const T *tw, 
     a.steps = d.B * a.sps;
     a.tbl = d.tbl; a.reach = 0;
     if (d.tbl) { a.stp = 0; a.ss0 = 0; a.rd_shift = 0; a.reach = (fps == 1) ? 0 : d.tbl_reach; }
-    if (Q == 4 && r512x_ring<T>(d)) { return launch_r512x_ring<T>(Y, X, win, tw, a, d, s); }
+    if (r512x_ring<T>(d)) {
+#if R512X_RING_1024
+        if (Q == 2) { return launch_r512x_ring<T, 2>(Y, X, win, tw, a, d, s); }
+#endif
+        return launch_r512x_ring<T, 4>(Y, X, win, tw, a, d, s);
+    }
     if (Q == 4) { return launch_r512x_shape<T, 4, 2048, true>(Y, X, win, tw, a, d, s); }
     if (d.tbl || (d.stp & 1)) { return launch_r512x_shape<T, 2, 2048, false>(Y, X, win, tw, a, d, s); }
     if (d.stp + 1024 <= 1280) { return launch_r512x_shape<T, 2, 1280, true>(Y, X, win, tw, a, d, s); }
@@ -735,9 +764,13 @@ static hipError_t launch_r512x_cplx_any(T *Y, const T *X, const T *win, const T 
     a.steps = d.B * a.sps;
     a.tbl = nullptr; a.reach = 0;
     a.cscale = scale;
-    if (Q == 4 && r512x_ring<T>(d)) {
-        a.sps = (d.W + R512X_UNIT - 1) / R512X_UNIT;
+    if (r512x_ring<T>(d)) {
+        const int fpu = R512X_UNIT * fps;
+        a.sps = (d.W + fpu - 1) / fpu;
         a.steps = d.B * a.sps;
+#if R512X_RING_1024
+        if (Q == 2) { return launch_r512x_inst<T, 2, true, false, false, 2048, true, true, true>(Y, X, win, tw, a, s); }
+#endif
         return launch_r512x_inst<T, 4, true, false, false, 2048, true, true, true>(Y, X, win, tw, a, s);
     }
     if (Q == 4) { return launch_r512x_cplx_shape<T, 4, 2048, true>(Y, X, win, tw, a, d, s); }

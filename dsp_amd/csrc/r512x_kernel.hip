@@ -108,6 +108,9 @@ __device__ __forceinline__ double r512x_from_lane(double v, int addr)
 {
     return __hiloint2double(__builtin_amdgcn_ds_bpermute(addr, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(addr, __double2loint(v)));
 }
+#ifndef R512X_BPERM_AHEAD
+#define R512X_BPERM_AHEAD 1     // 1: (power form) the 16 ds_bpermute of a step are issued before the first result is used
+#endif
 #ifndef R512X_BPERM
 #define R512X_BPERM (Q == 4)    // the split fetches its partner values with one ds_bpermute each instead of DPP moves, half-wave swaps and selects
                                 // (measured: nfft 2048 -2.4 % float32, -6.6 % float64; nfft 1024, whose partners need no half-wave swap, +4 % / +1.5 %)
@@ -542,6 +545,17 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
         } else {
             T pw[16];                                          // pw[k2] = P[K], pw[8 + k2] = P[M - K]
             T pmid = T(4) * cx_norm<T>(zz[slot16(8)]);         // K = M / 2: lane j == 0 of group 0 only
+            // the partner values by ds_bpermute: all of them asked for before the first is used (fetched pair by pair inside
+            // the loop, each pair was waited for on the spot: 8 LDS round trips in a row)
+            [[maybe_unused]] C mm[8];
+            if constexpr (R512X_BPERM && R512X_BPERM_AHEAD) {
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) {
+                    const C oth = zz[slot16(15 - k2)];
+                    mm[k2] = C{r512x_from_lane(oth.x, paddr), r512x_from_lane(oth.y, paddr)};
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int k2 = 0; k2 < 8; ++k2) {
                 if constexpr (R512X_LOAD_SPREAD == 4) { span_piece(k2); }
@@ -550,7 +564,9 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
                 // select replaces by register (16 - k2) % 16)
                 const C own = zz[slot16((16 - k2) & 15)], oth = zz[slot16(15 - k2)];
                 C m;
-                if constexpr (R512X_BPERM) {
+                if constexpr (R512X_BPERM && R512X_BPERM_AHEAD) {
+                m = mm[k2];
+                } else if constexpr (R512X_BPERM) {
                 m = C{r512x_from_lane(oth.x, paddr), r512x_from_lane(oth.y, paddr)};
                 } else {
                 const T mx1 = r512x_mirror(oth.x), my1 = r512x_mirror(oth.y);

@@ -109,7 +109,7 @@ __device__ __forceinline__ double r512x_from_lane(double v, int addr)
     return __hiloint2double(__builtin_amdgcn_ds_bpermute(addr, __double2hiint(v)), __builtin_amdgcn_ds_bpermute(addr, __double2loint(v)));
 }
 #ifndef R512X_DIRECT_STORE
-#define R512X_DIRECT_STORE 1    // 1: nfft 2048, float64, power form: rows stored straight from the registers, 64 consecutive values per instruction
+#define R512X_DIRECT_STORE 1    // 1: float64, power form: rows stored straight from the registers
 #endif
 #ifndef R512X_BPERM_AHEAD
 #define R512X_BPERM_AHEAD 1     // 1: (power form) the 16 ds_bpermute of a step are issued before the first result is used
@@ -202,11 +202,11 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
     constexpr int WAVE_LDS = R512X_TILE + SPAN;
     constexpr int ROWF = CPLX ? 2 * F : F;                 // values of an output row
     constexpr int NVI = (FPS * ROWF + 255) / 256;          // float32: whole-vector wave stores of a step's block of rows
-    // nfft 2048, float64, power form: the rows leave straight from the registers (the 64 lanes of a wave hold 64 consecutive bins of
-    // every k2: K = 64 k2 + 4 j + r), 17 store instructions of 512 bytes; otherwise they are staged in LDS in output order.  (Measured
-    // on 64 x 60 s @ 44.1 kHz, hop 512: float64 1.179 -> 1.059 ms; float32, whose staged rows leave as 6 stores of 16 bytes per lane,
-    // 0.529 -> 0.545 ms with it: float64 only.)
-    constexpr bool DIRECT = R512X_DIRECT_STORE && Q == 4 && !CPLX && !F32;
+    // float64, power form: the rows leave straight from the registers (the lanes of a frame hold consecutive bins of every k2:
+    // K = 16 Q k2 + Q j + r), 17 store instructions; otherwise they are staged in LDS in output order.  (Measured on 64 x 60 s @
+    // 44.1 kHz, nfft 2048 / hop 512: float64 1.179 -> 1.059 ms; float32, whose staged rows leave as 6 stores of 16 bytes per lane,
+    // 0.529 -> 0.545 ms with it: float64 only; nfft 1024 / hop 256 float64 1.10 -> 1.04 ms.)
+    constexpr bool DIRECT = R512X_DIRECT_STORE && !CPLX && !F32;
     constexpr int NSTORE = DIRECT ? 17 : F32 ? NVI + 1 : (FPS * ROWF + 63) / 64;   // store instructions per step
     static_assert(FPS * ROWF + 3 <= R512X_TILE, "row staging fits the tile");
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -599,19 +599,25 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
             wave_sync();                                       // every lane has read its tile row: reuse the region
             R512X_STAMP(5);                                    // split
             if constexpr (DIRECT) {
-                T *const yk = yblk + 4 * j + r;
+                // bin M / 2 of a frame is held by lane j = 0 of its group of residue 0; every lane of the frame stores it
+                auto bcast = [&](const int src) {
+                    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint((double)pmid), src), __builtin_amdgcn_readlane(__double2loint((double)pmid), src));
+                };
+                T mid = (T)bcast(16 * (Q - 1));
+                if constexpr (FPS == 2) { const T mid1 = (T)bcast(16 * (2 * Q - 1)); mid = f ? mid1 : mid; }
+                T *const yk = yblk + f * ROWF + Q * j + r;         // K = 16 Q k2 + Q j + r
+                // (a last step with one frame: the lanes of the second do not store; the instructions are issued all the same, which is
+                // what the counted wait of the next span relies on)
+                if (FPS == 1 || f * ROWF < nout) {
 #pragma unroll
-                for (int k2 = 0; k2 < 8; ++k2) {
-                    if constexpr (R512X_NOSTORE == 0) {
-                        __builtin_nontemporal_store(pw[k2], yk + 64 * k2);
-                        __builtin_nontemporal_store(pw[8 + k2], yblk + M - 4 * j - r - 64 * k2);
+                    for (int k2 = 0; k2 < 8; ++k2) {
+                        if constexpr (R512X_NOSTORE == 0) {
+                            __builtin_nontemporal_store(pw[k2], yk + 16 * Q * k2);
+                            __builtin_nontemporal_store(pw[8 + k2], yblk + f * ROWF + M - Q * j - r - 16 * Q * k2);
+                        }
                     }
+                    if constexpr (R512X_NOSTORE == 0) { __builtin_nontemporal_store(mid, yblk + f * ROWF + M / 2); }
                 }
-                // bin M / 2 is held by lane j = 0 of the group of residue 0 (lane 48); every lane stores it (no branch around a store)
-                T mid;
-                if constexpr (F32) { mid = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pmid), 48)); }
-                else { mid = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pmid), 48), __builtin_amdgcn_readlane(__double2loint(pmid), 48)); }
-                if constexpr (R512X_NOSTORE == 0) { __builtin_nontemporal_store(mid, yblk + M / 2); }
             } else {
                 T *pf = xs + sh + f * F;
 #pragma unroll

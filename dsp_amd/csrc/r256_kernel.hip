@@ -38,6 +38,7 @@ struct R256Args {
     int edge;             // 0 reflect, 1 zero
     Epilogue epi;
     int sps;              // steps (groups of 8 consecutive frames) per signal
+    FastDiv spd;          // ... as a divisor
     int steps;            // B * sps
     const int *tbl;       // table form: start of frame w at tbl[2 w] (frames need not be equally spaced); else nullptr
     int reach;            // table form: bound on the distance between the starts of the first and last frame of a step
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(64 * r256_waves<T>(), sizeof(T) == 4 ? 2 : 1) void 
     const int round = nwg_x * NWV, first = s_lo + (blockIdx.x >> 3) * NWV;
     int sid = first + wv;
     if (sid >= s_hi) { return; }
-    int b = sid / a.sps;
+    int b = (int)a.spd.div((unsigned)sid);
     int w = (sid - b * a.sps) * FPS;
     const T *xb = X + (long long)b * a.ldx;
     T *yb = Y + (long long)b * a.Wy * ROWF;
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(64 * r256_waves<T>(), sizeof(T) == 4 ? 2 : 1) void 
         nsid = first + (t / NWV) * round + (t % NWV);
         more = nsid < s_hi;
         if (more) {
-            const int nb = nsid / a.sps;
+            const int nb = (int)a.spd.div((unsigned)nsid);
             nw = (nsid - nb * a.sps) * FPS;
             nxb = X + (long long)nb * a.ldx;
             nyb = Y + (long long)nb * a.Wy * ROWF;
@@ -460,6 +461,7 @@ static hipError_t launch_r256_cl(T *Y, const T *X, const T *win, const T *tw, co
     a.ldx = d.ldx; a.N = (int)d.N; a.L = d.L; a.W = d.W; a.Wy = d.wy(); a.stp = d.stp; a.ss0 = (int)d.ss0;
     a.rd_shift = (int)d.rd_shift; a.edge = d.edge; a.epi = d.epi;
     a.sps = (d.W + FPS - 1) / FPS;
+    a.spd = FastDiv::of((unsigned)a.sps);
     a.steps = d.B * a.sps;
     a.tbl = d.tbl; a.reach = 0;
     a.cscale = scale;

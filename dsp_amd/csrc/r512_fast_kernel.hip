@@ -36,6 +36,7 @@ struct R512FastArgs {
     int edge;             // 0 reflect, 1 zero
     Epilogue epi;
     int sps;              // steps (groups of 4 consecutive frames) per signal
+    FastDiv spd;          // ... as a divisor
     int steps;            // B * sps
     const int *tbl;       // table form: start of frame w at tbl[2 w] (frames need not be equally spaced)
     int all16;            // every step has 4 frames and its block of rows is 16-byte aligned
@@ -77,6 +78,9 @@ template <> struct vec16u<float> { typedef float type __attribute__((ext_vector_
 template <> struct vec16u<double> { typedef double type __attribute__((ext_vector_type(2), aligned(8))); };
 
 #ifndef R512F_TW_LDS
+#ifndef R512F_GLDS_SPLIT
+#define R512F_GLDS_SPLIT 1      // 1: the span's LDS-DMA loads take their addresses as scalar base + 32-bit lane offset (ring_glds16_at)
+#endif
 #define R512F_TW_LDS 0          // 1: pass-1 twiddles come from an LDS table instead of 30 registers
 #endif
 #ifndef R512F_WIN_LDS
@@ -281,6 +285,7 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
         const T *src = xb + (s0 - (a.edge ? a.rd_shift : 0));
         const bool inside = s0 >= 0 && s0 + SPAN + ((WIDE == 2 && !TBL) ? 3 * a.gap : 0) <= a.N && (a.edge == 0 || s0 >= a.rd_shift);
         if constexpr (RING) {
+            [[maybe_unused]] const unsigned lds_slot = __builtin_amdgcn_readfirstlane(ring_lds_addr(slot));
             // NV LDS-DMA loads per span whatever the case (the counted wait relies on that): behind a gathered
             // span NV placeholder loads follow, from the twiddle table into `dummy`
             if (inside) {
@@ -290,7 +295,11 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
 #if R512F_NOLOAD
                     ring_glds16(tw + lane * VEC, __builtin_amdgcn_readfirstlane(ring_lds_addr(dummy)));
 #else
+#if R512F_GLDS_SPLIT
+                    ring_glds16_at(ring_uniform(src), (unsigned)sizeof(T) * (unsigned)span_off(min(q * 64 + lane, nvec - 1) * VEC), lds_slot, 1024 * q);
+#else
                     ring_glds16(src + span_off(min(q * 64 + lane, nvec - 1) * VEC), __builtin_amdgcn_readfirstlane(ring_lds_addr(slot + q * 64 * VEC)));
+#endif
 #endif
                 }
             } else {
@@ -346,8 +355,9 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
     int sid = first + (wv >> 3) * round + (wv & 7);      // draw number wv
     if (sid >= s_hi) { return; }
     // (ILV: sps is the number of channel groups, which run fastest; b is the group, w the frame)
-    int b = ILV ? sid % a.sps : sid / a.sps;
-    int w = ILV ? sid / a.sps : (sid - b * a.sps) * 4;
+    const int q0 = (int)a.spd.div((unsigned)sid);
+    int b = ILV ? sid - q0 * a.sps : q0;
+    int w = ILV ? q0 : (sid - b * a.sps) * 4;
     const T *xb = ILV ? X + 4 * b : X + (long long)b * a.ldx;
     T *yb = Y + (long long)(ILV ? 4 * b : b) * a.Wy * ROWF;
 
@@ -363,8 +373,9 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
         nsid = first + (t >> 3) * round + (t & 7);
         more = nsid < s_hi;
         if (more) {
-            const int nb = ILV ? nsid % a.sps : nsid / a.sps;
-            nw = ILV ? nsid / a.sps : (nsid - nb * a.sps) * 4;
+            const int nq = (int)a.spd.div((unsigned)nsid);
+            const int nb = ILV ? nsid - nq * a.sps : nq;
+            nw = ILV ? nq : (nsid - nb * a.sps) * 4;
             nxb = ILV ? X + 4 * nb : X + (long long)nb * a.ldx;
             nyb = Y + (long long)(ILV ? 4 * nb : nb) * a.Wy * ROWF;
         }
@@ -740,6 +751,7 @@ static hipError_t launch_stft_r512_fast_one(T *Y, const T *X, const T *win, cons
     a.ldx = d.ldx; a.N = (int)d.N; a.L = d.L; a.W = d.W; a.stp = d.stp; a.ss0 = (int)d.ss0;
     a.rd_shift = (int)d.rd_shift; a.edge = d.edge; a.epi = d.epi;
     a.sps = (d.W + 3) / 4;
+    a.spd = FastDiv::of((unsigned)a.sps);
     a.steps = d.B * a.sps;
     a.tbl = d.tbl;
     a.gap = (!d.tbl && d.stp > 512) ? d.stp - 512 : 0;
@@ -822,6 +834,7 @@ hipError_t launch_stft_r512_fast_ilv(float *Y, const float *X, const float *win,
     a.ldx = (long long)pitch; a.N = (int)d.N; a.L = d.L; a.W = d.W; a.stp = d.stp; a.ss0 = (int)d.ss0;
     a.rd_shift = 0; a.edge = 0; a.epi = d.epi;
     a.sps = d.B / 4;                                       // channel groups
+    a.spd = FastDiv::of((unsigned)a.sps);
     a.steps = a.sps * d.W;
     a.Wy = d.wy();
     const bool epi = d.epi.any();
@@ -848,6 +861,7 @@ hipError_t launch_stft_r512_fast_cplx(T *Y, const T *X, const T *win, const T *t
     a.ldx = d.ldx; a.N = (int)d.N; a.L = d.L; a.W = d.W; a.stp = d.stp; a.ss0 = (int)d.ss0;
     a.rd_shift = (int)d.rd_shift; a.edge = d.edge; a.epi = d.epi;
     a.sps = (d.W + 3) / 4;
+    a.spd = FastDiv::of((unsigned)a.sps);
     a.steps = d.B * a.sps;
     a.tbl = nullptr;
     a.gap = d.stp > 512 ? d.stp - 512 : 0;

@@ -42,6 +42,7 @@ struct R512XArgs {
     int edge;             // 0 reflect, 1 zero
     Epilogue epi;
     int sps;              // steps per signal
+    FastDiv spd;          // ... as a divisor
     int steps;            // B * sps
     const int *tbl;       // table form: start of frame w at tbl[2 w] (frames need not be equally spaced); else nullptr
     int reach;            // table form: bound on the distance between the starts of the first and last frame of a step
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
     const int round = nwg_x * NWV, first = s_lo + (blockIdx.x >> 3) * NWV;
     int sid = first + wv;
     if (sid >= s_hi) { return; }
-    int b = sid / a.sps;
+    int b = (int)a.spd.div((unsigned)sid);
     int w = (sid - b * a.sps) * FPU;
     [[maybe_unused]] int t = 0, ulen = RQ ? (min(FPU, a.W - w) + FPS - 1) / FPS : 1;      // RQ: the step inside the unit, the unit's steps
     // RQ: 512-sample blocks between two steps (nfft 2048: hop 512: 1, hop 1024: 2; nfft 1024, two frames per step at hop 256: 1)
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
         nsid = first + (t / NWV) * round + (t % NWV);
         more = nsid < s_hi;
         if (more) {
-            const int nb = nsid / a.sps;
+            const int nb = (int)a.spd.div((unsigned)nsid);
             nw = (nsid - nb * a.sps) * FPU;
             nxb = X + (long long)nb * a.ldx;
             nyb = Y + (long long)nb * a.Wy * ROWF;
@@ -620,11 +621,12 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
                 }
             } else {
                 T *pf = xs + sh + f * F;
+                // (K = 16 Q k2 + Q j + r: both runs of addresses as one base and constant offsets that are not negative)
+                T *const pk = pf + (Q * j + r), *const pm = pf + (M - 16 * Q * 7) - (Q * j + r);
 #pragma unroll
                 for (int k2 = 0; k2 < 8; ++k2) {
-                    const int K = Q * (j + 16 * k2) + r;
-                    pf[K] = pw[k2];
-                    pf[M - K] = pw[8 + k2];
+                    pk[16 * Q * k2] = pw[k2];
+                    pm[16 * Q * (7 - k2)] = pw[8 + k2];
                 }
                 if (own0) { pf[M / 2] = pmid; }
             }
@@ -723,6 +725,7 @@ static hipError_t launch_r512x_ring(T *Y, const T *X, const T *win, const T *tw,
 {
     constexpr int fpu = R512X_UNIT * (4 / Q);
     a.sps = (d.W + fpu - 1) / fpu;                          // units per signal
+    a.spd = FastDiv::of((unsigned)a.sps);
     a.steps = d.B * a.sps;
     const bool epi = d.epi.any();
 #define DSP_R512Q(M_, E_) launch_r512x_inst<T, Q, true, M_, E_, 2048, true, false, true>(Y, X, win, tw, a, s)
@@ -758,6 +761,7 @@ static hipError_t launch_r512x_any(T *Y, const T *X, const T *win, const T *tw, 
     a.ldx = d.ldx; a.N = (int)d.N; a.L = d.L; a.W = d.W; a.Wy = d.wy(); a.stp = d.stp; a.ss0 = (int)d.ss0;
     a.rd_shift = (int)d.rd_shift; a.edge = d.edge; a.epi = d.epi;
     a.sps = (d.W + fps - 1) / fps;
+    a.spd = FastDiv::of((unsigned)a.sps);
     a.steps = d.B * a.sps;
     a.tbl = d.tbl; a.reach = 0;
     if (d.tbl) { a.stp = 0; a.ss0 = 0; a.rd_shift = 0; a.reach = (fps == 1) ? 0 : d.tbl_reach; }
@@ -806,12 +810,14 @@ static hipError_t launch_r512x_cplx_any(T *Y, const T *X, const T *win, const T 
     a.ldx = d.ldx; a.N = (int)d.N; a.L = d.L; a.W = d.W; a.Wy = d.wy(); a.stp = d.stp; a.ss0 = (int)d.ss0;
     a.rd_shift = (int)d.rd_shift; a.edge = d.edge; a.epi = d.epi;
     a.sps = (d.W + fps - 1) / fps;
+    a.spd = FastDiv::of((unsigned)a.sps);
     a.steps = d.B * a.sps;
     a.tbl = nullptr; a.reach = 0;
     a.cscale = scale;
     if (r512x_ring<T>(d)) {
         const int fpu = R512X_UNIT * fps;
         a.sps = (d.W + fpu - 1) / fpu;
+        a.spd = FastDiv::of((unsigned)a.sps);
         a.steps = d.B * a.sps;
 #if R512X_RING_1024
         if (Q == 2) { return launch_r512x_inst<T, 2, true, false, false, 2048, true, true, true>(Y, X, win, tw, a, s); }

@@ -28,6 +28,31 @@ __device__ __forceinline__ unsigned ring_lds_addr(const void *p)
 {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
 }
+// The same load with its addresses split into wave-uniform parts and small per-lane parts: memory address = base (scalar
+// registers) + voff bytes (32 bits per lane), LDS address = lds (scalar) + lds_off (a constant once the call is unrolled).  Three
+// instructions -- M0, the wait state that a write of M0 needs, the load -- where the form above takes eight with the 64-bit
+// address arithmetic in front of it; a wave issues one instruction of any kind every four cycles, and these kernels spend more
+// than half of their time issuing.  M0 is left changed: the compiler keeps nothing in it on this target unless a kernel indexes
+// registers or sends messages, which these do not (tools/asm_waits.py checks on the built library that nothing else touches M0
+// in a kernel that holds such a load).
+#ifndef DSP_GLDS_SPLIT
+#define DSP_GLDS_SPLIT 1
+#endif
+template <typename P> __device__ __forceinline__ const P *ring_uniform(const P *p)     // a wave-uniform pointer, into scalar registers
+{
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const P *>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void ring_glds16_at(const void *base, const unsigned voff, const unsigned lds, const int lds_off)
+{
+#if DSP_GLDS_SPLIT
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff), "s"(base), "s"(lds), "n"(lds_off) : "memory", "scc");
+#else
+    ring_glds16(reinterpret_cast<const char *>(base) + voff, lds + lds_off);
+#endif
+}
 // The counted wait: until at most N memory operations of the wave are outstanding.  Memory operations complete in
 // issue order, so with exactly N store instructions issued behind a span's loads this waits for the span and leaves
 // the stores in flight.  The count is an assumption about the code the compiler emits between the two points; it is
@@ -72,6 +97,9 @@ __device__ __forceinline__ void ring_store_rows(float *__restrict__ yblk, const 
 {
     typedef float f4nt __attribute__((ext_vector_type(4)));
     const int nb = (nout - head) >> 2, tail = nout - head - 4 * nb;
+    // (The same split of the addresses as in ring_glds16_at -- a wave-uniform base in scalar registers plus a 32-bit offset per lane,
+    // two vector instructions of address arithmetic per store instead of five -- measured 3.5 % SLOWER on the 1024- and 2048-point
+    // kernels, 0.456 -> 0.472 and 0.509 -> 0.532 ms: the stores stay on 64-bit addresses per lane.)
 #pragma unroll
     for (int i = 0; i < NVI; ++i) {
         const int v = min(lane + 64 * i, nb - 1);
@@ -97,15 +125,17 @@ __device__ __forceinline__ void ring_load_span(T *slot, T *dummy, const T *tw, c
     constexpr int VEC = 16 / (int)sizeof(T);
     typedef T vecT __attribute__((ext_vector_type(VEC)));
     const int nvec = (need + VEC - 1) / VEC;
-    const T *src = xb + (s0 - (edge ? rd_shift : 0));
+    const T *src = ring_uniform(xb + (s0 - (edge ? rd_shift : 0)));
     const bool inside = s0 >= 0 && s0 + VEC * nvec <= N && (edge == 0 || s0 >= rd_shift);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(ring_lds_addr(slot));
     if (inside) {
+        const unsigned last = 16u * (unsigned)(nvec - 1);
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
 #ifdef RING_FAKE_NV
             if (q >= RING_FAKE_NV) { continue; }       // diagnostic builds: fewer loads (wrong results)
 #endif
-            ring_glds16(src + min(q * 64 + lane, nvec - 1) * VEC, __builtin_amdgcn_readfirstlane(ring_lds_addr(slot + q * 64 * VEC)));
+            ring_glds16_at(src, min(1024u * q + 16u * lane, last), lds0, 1024 * q);
         }
     } else {
 #pragma clang loop unroll(disable)
@@ -118,8 +148,9 @@ __device__ __forceinline__ void ring_load_span(T *slot, T *dummy, const T *tw, c
             }
             reinterpret_cast<vecT *>(slot)[q * 64 + lane] = t;
         }
+        const unsigned ldsd = __builtin_amdgcn_readfirstlane(ring_lds_addr(dummy));
 #pragma unroll
-        for (int q = 0; q < NV; ++q) { ring_glds16(tw + lane * VEC, __builtin_amdgcn_readfirstlane(ring_lds_addr(dummy))); }
+        for (int q = 0; q < NV; ++q) { ring_glds16_at(ring_uniform(tw), 16u * lane, ldsd, 0); }
     }
 }
 

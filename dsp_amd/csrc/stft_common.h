@@ -15,6 +15,33 @@ namespace dsp {
 // What happens to a power value before it is stored: [sqrt] -> [log] -> [power compression].
 // pc selects the compression of reference c/pow_compress.c:23-50 applied to v + preg:
 // 0 none, 1 identity (v + preg), 2 log, 3 sqrt, 4 cbrt, 5 pow(., p).
+// Division of a step number by a divisor that is fixed for the launch: multiplication by a 33-bit reciprocal made on the host
+// (Granlund and Montgomery's round-up form), exact for every 32-bit dividend.  On wave-uniform operands it is five scalar
+// instructions where the compiler's division by a run-time value takes about 25, in kernels that draw a step number per step.
+struct FastDiv {
+    unsigned m = 1;
+    int sh1 = 0, sh2 = 0;
+    static FastDiv of(unsigned d)
+    {
+        FastDiv r;
+        int s = 0;
+        while ((1ull << s) < d) { ++s; }
+        r.m = (unsigned)((((1ull << s) - d) << 32) / d + 1);
+        r.sh1 = s < 1 ? s : 1;
+        r.sh2 = s > 1 ? s - 1 : 0;
+        return r;
+    }
+    __host__ __device__ unsigned div(unsigned n) const
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const unsigned t = __umulhi(n, m);
+#else
+        const unsigned t = (unsigned)(((unsigned long long)n * m) >> 32);
+#endif
+        return (t + ((n - t) >> sh1)) >> sh2;
+    }
+};
+
 struct Epilogue {
     int amp, lg, pc;
     double p, preg;

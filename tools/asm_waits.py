@@ -8,7 +8,8 @@ emitted fewer stores on some path than N, the wait would return before the span 
 code objects out of libdsp_stft_hip.so, disassembles them with llvm-objdump and reports, for every kernel that has such
 waits: the N of those waits, the number of store instructions in every store sequence (what one pass through a step can
 issue; see analyse) and the number of LDS-DMA loads per load sequence.  The sets of the first two must be equal, the third
-one number.
+one number.  It also reports any instruction that depends on M0 apart from those loads: the newer load form writes M0 before
+every load and does not restore it.
 
     python tools/asm_waits.py [library]        prints one line per kernel and the verdict; exit code 1 on a mismatch
 """
@@ -143,6 +144,26 @@ def analyse(insns):
     return waits, seqs, dmas
 
 
+IMPLICIT_M0 = ("s_movrel", "v_movrel", "s_sendmsg", "ds_gws", "v_interp", "s_set_gpr_idx", "ds_param_load", "ds_direct_load")
+
+
+def m0_readers(insns):
+    """Instructions of a kernel, other than its LDS-DMA loads, that depend on the contents of M0.  ring_glds16_at writes M0 and
+    leaves it changed, on the assumption that the compiler keeps nothing there: holds as long as this list is empty.  (Copies of
+    M0 into a scalar register -- the older load form saves and restores it -- do not depend on what it holds.)"""
+    out = []
+    for addr, op, args in insns:
+        if op.startswith("global_load_lds"):
+            continue
+        if op.startswith(IMPLICIT_M0):
+            out.append(f"{op} {args}")
+            continue
+        srcs = [a.strip() for a in args.split(",")[1:]]
+        if "m0" in srcs and not (op == "s_mov_b32" and args.split(",")[0].strip().startswith("s")):
+            out.append(f"{op} {args}")
+    return out
+
+
 def check(lib):
     """List of (kernel, waits, store sequences, LDS-DMA sequences, problem or None) for every kernel with counted waits."""
     rows = []
@@ -165,6 +186,9 @@ def check(lib):
             d = sorted(set(dmas))
             if not (len(d) == 1 or ("stft_r512x_kernel" in name and all(v in (d[-1] // 4, d[-1] // 2, d[-1]) for v in d))):
                 problems.append(f"LDS-DMA loads per sequence: {d} (one fixed number expected, or NV / 4, NV / 2 and NV in the ring form)")
+            m0 = m0_readers(insns)
+            if m0:
+                problems.append(f"M0 is read outside the LDS-DMA loads: {m0[:3]}")
             rows.append((name, sorted(set(waits)), sorted(seqs), sorted(set(dmas)), "; ".join(problems) or None))
     return rows
 

@@ -565,33 +565,49 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int k2 = 0; k2 < 8; ++k2) {
-                if constexpr (R512X_LOAD_SPREAD == 4) { span_piece(k2); }
-                const C z = zz[slot16(k2)];
-                // (lane 0 of residue 0 is its own partner: the moves hand it its own register 15 - k2, which the last
-                // select replaces by register (16 - k2) % 16)
+            // (lane 0 of residue 0 is its own partner: the moves hand it its own register 15 - k2, which the last
+            // select replaces by register (16 - k2) % 16)
+            auto partner = [&](const int k2) __attribute__((always_inline)) {
                 const C own = zz[slot16((16 - k2) & 15)], oth = zz[slot16(15 - k2)];
                 C m;
                 if constexpr (R512X_BPERM && R512X_BPERM_AHEAD) {
-                m = mm[k2];
+                    m = mm[k2];
                 } else if constexpr (R512X_BPERM) {
-                m = C{r512x_from_lane(oth.x, paddr), r512x_from_lane(oth.y, paddr)};
+                    m = C{r512x_from_lane(oth.x, paddr), r512x_from_lane(oth.y, paddr)};
                 } else {
-                const T mx1 = r512x_mirror(oth.x), my1 = r512x_mirror(oth.y);
-                const T mx2 = r512x_ror1(mx1), my2 = r512x_ror1(my1);
-                if constexpr (Q == 2) {
-                    m = C{r == 0 ? mx2 : mx1, r == 0 ? my2 : my1};
-                } else {
-                    const T mx3 = r512x_xor32(mx1, lane < 32), my3 = r512x_xor32(my1, lane < 32);
-                    m = C{r == 0 ? mx2 : (r == 2 ? mx1 : mx3), r == 0 ? my2 : (r == 2 ? my1 : my3)};
+                    const T mx1 = r512x_mirror(oth.x), my1 = r512x_mirror(oth.y);
+                    const T mx2 = r512x_ror1(mx1), my2 = r512x_ror1(my1);
+                    if constexpr (Q == 2) {
+                        m = C{r == 0 ? mx2 : mx1, r == 0 ? my2 : my1};
+                    } else {
+                        const T mx3 = r512x_xor32(mx1, lane < 32), my3 = r512x_xor32(my1, lane < 32);
+                        m = C{r == 0 ? mx2 : (r == 2 ? mx1 : mx3), r == 0 ? my2 : (r == 2 ? my1 : my3)};
+                    }
                 }
-                }
-                m = C{own0 ? own.x : m.x, own0 ? own.y : m.y};
-                const C A = cx_add_conj<T>(z, m), B = cx_sub_conj<T>(z, m);
-                const C Tw = cx_mul<T>(B, ow[k2]);
-                pw[k2] = cx_norm<T>(A + Tw);
-                pw[8 + k2] = cx_norm<T>(A - Tw);
+                return C{own0 ? own.x : m.x, own0 ? own.y : m.y};
+            };
+            // two bins at a time, stage by stage: a packed instruction that consumes the result of the one issued just before it
+            // costs a wait state, and the stages of one bin are such a chain
+            const C pm = C{T(1), T(-1)};
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                if constexpr (R512X_LOAD_SPREAD == 4) { span_piece(2 * h); span_piece(2 * h + 1); }
+                const int ka = h, kb = h + 4;
+                const C ma = partner(ka), mb = partner(kb);
+                const C za = zz[slot16(ka)], zb = zz[slot16(kb)];
+                const C Aa = cx_add_conj<T>(za, ma), Ab = cx_add_conj<T>(zb, mb);
+                const C Ba = cx_sub_conj<T>(za, ma), Bb = cx_sub_conj<T>(zb, mb);
+                const C ta = cx_mul_first<T>(Ba, ow[ka]), tb = cx_mul_first<T>(Bb, ow[kb]);
+                const C Ta = cx_mul_second<T>(Ba, ow[ka], ta), Tb = cx_mul_second<T>(Bb, ow[kb], tb);
+                // (|A + T|^2, |A - T|^2) as one pair: the real parts of both sums in one packed register, the imaginary parts in
+                // another (x * 1 + y is x + y exactly: the bits of cx_norm(A + T), cx_norm(A - T))
+                const C rea = cx_fma(C{Ta.x, Ta.x}, pm, C{Aa.x, Aa.x}), reb = cx_fma(C{Tb.x, Tb.x}, pm, C{Ab.x, Ab.x});
+                const C ima = cx_fma(C{Ta.y, Ta.y}, pm, C{Aa.y, Aa.y}), imb = cx_fma(C{Tb.y, Tb.y}, pm, C{Ab.y, Ab.y});
+                const C qa = rea * rea, qb = reb * reb;
+                const C ra = ima * ima, rb = imb * imb;
+                const C pa = qa + ra, pb = qb + rb;
+                pw[ka] = pa.x; pw[8 + ka] = pa.y;
+                pw[kb] = pb.x; pw[8 + kb] = pb.y;
             }
             if (EPI) {
                 power_epilogue_n(pw, a.epi);

@@ -26,6 +26,7 @@ __device__ __forceinline__ void ring_glds16(const void *g, const unsigned lds)
 }
 __device__ __forceinline__ unsigned ring_lds_addr(const void *p)
 {
+    __builtin_assume(p != nullptr);          // (no test for the null pointer in the conversion)
     return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
 }
 // The same load with its addresses split into wave-uniform parts and small per-lane parts: memory address = base (scalar
@@ -100,12 +101,15 @@ __device__ __forceinline__ void ring_store_rows(float *__restrict__ yblk, const 
     // (The same split of the addresses as in ring_glds16_at -- a wave-uniform base in scalar registers plus a 32-bit offset per lane,
     // two vector instructions of address arithmetic per store instead of five -- measured 3.5 % SLOWER on the 1024- and 2048-point
     // kernels, 0.456 -> 0.472 and 0.509 -> 0.532 ms: the stores stay on 64-bit addresses per lane.)
+    // (unsigned vector numbers: the 64-bit address of a store is then one shift-and-add on the zero-extended number)
+    const f4nt *const sv = reinterpret_cast<const f4nt *>(stage + head);
+    f4nt *const gv = reinterpret_cast<f4nt *>(yblk + head);
 #pragma unroll
     for (int i = 0; i < NVI; ++i) {
-        const int v = min(lane + 64 * i, nb - 1);
-        const f4nt val = *reinterpret_cast<const f4nt *>(stage + head + 4 * v);
+        const unsigned v = min((unsigned)lane + 64u * i, (unsigned)(nb - 1));
+        const f4nt val = sv[v];
         if constexpr (SKIP) { asm volatile("" :: "v"(val)); }
-        else { __builtin_nontemporal_store(val, reinterpret_cast<f4nt *>(yblk + head + 4 * v)); }
+        else { __builtin_nontemporal_store(val, gv + v); }
     }
     int e = nout - 1;
     if (lane < head) { e = lane; }

@@ -1,5 +1,6 @@
 #!/bin/bash
-# SQ counter passes (each in a run of its own, never with a trace) for the three benchmark kernels; summaries under gpurun_out/pmc_sq.txt
+# SQ counter passes (each in a run of its own, never with a trace) for the three benchmark kernels, or for the pairs
+# <workload> <kernel-name substring> given as arguments; summaries under gpurun_out/pmc_sq.txt
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
 OUT=$R/gpurun_out/pmc_sq.txt; : > $OUT
@@ -18,5 +19,9 @@ for k,v in sorted(agg.items()): print(sys.argv[1], k, '%.6g' % (sum(v)/len(v)))
 PY
   done
 }
+if [ $# -ge 2 ]; then
+  while [ $# -ge 2 ]; do run $1 $2 || exit 1; shift 2; done
+  cat $OUT; exit 0
+fi
 run utt1024x10s_f32_hann400_hop160_nfft512 stft_r512_fast && run flt_f64_8ch_x_1h16k_povey400_hop160_nfft512 stft_r512_fast && run longwin_f32_8ch_x_1h48k_bh4096_hop1024_nfft4096 stft_r4096
 cat $OUT

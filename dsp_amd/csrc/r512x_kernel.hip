@@ -96,6 +96,15 @@ __device__ __forceinline__ float r512x_ror1(float v)         // lane (i - 1) % 1
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, true));
 }
+// ... in the rows of 16 lanes that ROWS names (bit i = row i of the wave) only; the other rows keep their own value
+template <int ROWS> __device__ __forceinline__ float r512x_ror1_rows(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x121, ROWS, 0xf, false));
+}
+template <int ROWS> __device__ __forceinline__ double r512x_ror1_rows(double v)
+{
+    return __hiloint2double(__float_as_int(r512x_ror1_rows<ROWS>(__int_as_float(__double2hiint(v)))), __float_as_int(r512x_ror1_rows<ROWS>(__int_as_float(__double2loint(v)))));
+}
 typedef unsigned r512x_u2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float r512x_xor32(float v, bool low_half)   // lane i ^ 32
 {
@@ -321,14 +330,14 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
     T *nyb = yb;
     bool more = false;
     auto advance = [&]() {
-        const int t = ring_drawn(drawn);
-        nsid = first + (t / NWV) * round + (t % NWV);
+        const unsigned t = (unsigned)ring_drawn(drawn);          // (unsigned: the division and the products below stay short)
+        nsid = first + (int)(t / NWV) * round + (int)(t % NWV);
         more = nsid < s_hi;
         if (more) {
-            const int nb = (int)a.spd.div((unsigned)nsid);
-            nw = (nsid - nb * a.sps) * FPU;
-            nxb = X + (long long)nb * a.ldx;
-            nyb = Y + (long long)nb * a.Wy * ROWF;
+            const unsigned nb = a.spd.div((unsigned)nsid);
+            nw = (nsid - (int)nb * a.sps) * FPU;
+            nxb = X + (unsigned long long)nb * (unsigned long long)a.ldx;
+            nyb = Y + (unsigned long long)nb * ((unsigned long long)a.Wy * ROWF);
         }
     };
 
@@ -531,10 +540,12 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
                 m = C{r512x_from_lane(oth.x, paddr), r512x_from_lane(oth.y, paddr)};
                 } else {
                 const T mx1 = r512x_mirror(oth.x), my1 = r512x_mirror(oth.y);
-                const T mx2 = r512x_ror1(mx1), my2 = r512x_ror1(my1);
                 if constexpr (Q == 2) {
-                    m = C{r == 0 ? mx2 : mx1, r == 0 ? my2 : my1};
+                    // residue 0 (the odd rows of 16 lanes) takes lane (16 - j) % 16, residue 1 lane 15 - j: the rotation by one lane in
+                    // the odd rows only, which the move itself can do
+                    m = C{r512x_ror1_rows<0xA>(mx1), r512x_ror1_rows<0xA>(my1)};
                 } else {
+                    const T mx2 = r512x_ror1(mx1), my2 = r512x_ror1(my1);
                     const T mx3 = r512x_xor32(mx1, lane < 32), my3 = r512x_xor32(my1, lane < 32);
                     m = C{r == 0 ? mx2 : (r == 2 ? mx1 : mx3), r == 0 ? my2 : (r == 2 ? my1 : my3)};
                 }
@@ -576,10 +587,12 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
                     m = C{r512x_from_lane(oth.x, paddr), r512x_from_lane(oth.y, paddr)};
                 } else {
                     const T mx1 = r512x_mirror(oth.x), my1 = r512x_mirror(oth.y);
-                    const T mx2 = r512x_ror1(mx1), my2 = r512x_ror1(my1);
                     if constexpr (Q == 2) {
-                        m = C{r == 0 ? mx2 : mx1, r == 0 ? my2 : my1};
+                        // residue 0 (the odd rows of 16 lanes) takes lane (16 - j) % 16, residue 1 lane 15 - j: the rotation by one lane in
+                        // the odd rows only, which the move itself can do
+                        m = C{r512x_ror1_rows<0xA>(mx1), r512x_ror1_rows<0xA>(my1)};
                     } else {
+                        const T mx2 = r512x_ror1(mx1), my2 = r512x_ror1(my1);
                         const T mx3 = r512x_xor32(mx1, lane < 32), my3 = r512x_xor32(my1, lane < 32);
                         m = C{r == 0 ? mx2 : (r == 2 ? mx1 : mx3), r == 0 ? my2 : (r == 2 ? my1 : my3)};
                     }

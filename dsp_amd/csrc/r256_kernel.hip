@@ -217,14 +217,14 @@ __global__ __launch_bounds__(64 * r256_waves<T>(), sizeof(T) == 4 ? 2 : 1) void 
     T *nyb = yb;
     bool more = false;
     auto advance = [&]() {
-        const int t = ring_drawn(drawn);
-        nsid = first + (t / NWV) * round + (t % NWV);
+        const unsigned t = (unsigned)ring_drawn(drawn);          // (unsigned: the division and the products below stay short)
+        nsid = first + (int)(t / NWV) * round + (int)(t % NWV);
         more = nsid < s_hi;
         if (more) {
-            const int nb = (int)a.spd.div((unsigned)nsid);
-            nw = (nsid - nb * a.sps) * FPS;
-            nxb = X + (long long)nb * a.ldx;
-            nyb = Y + (long long)nb * a.Wy * ROWF;
+            const unsigned nb = a.spd.div((unsigned)nsid);
+            nw = (nsid - (int)nb * a.sps) * FPS;
+            nxb = X + (unsigned long long)nb * (unsigned long long)a.ldx;
+            nyb = Y + (unsigned long long)nb * ((unsigned long long)a.Wy * ROWF);
         }
     };
 
@@ -348,17 +348,27 @@ __global__ __launch_bounds__(64 * r256_waves<T>(), sizeof(T) == 4 ? 2 : 1) void 
         } else {
             T pw[16];                                          // [(r CL/2 + k2) 2]: P[K], [.. + 1]: P[M - K]
             T pmid = T(4) * cx_norm<T>(zr[0][r256_slot<CL>(CL / 2)]);  // K = M/2: lane j == 0 only
+            // two bins at a time, stage by stage (a packed instruction that consumes the result of the one issued just before it
+            // costs a wait state, and the stages of one bin are such a chain); (|A + T|^2, |A - T|^2) as one pair: the real parts
+            // of both sums in one packed register, the imaginary parts in another (x * 1 + y is x + y exactly)
+            const C pm = C{T(1), T(-1)};
 #pragma unroll
-            for (int r = 0; r < RW; ++r) {
-#pragma unroll
-                for (int k2 = 0; k2 < CL / 2; ++k2) {
-                    const C z = zr[r][r256_slot<CL>(k2)];
-                    const C m = partner(r, k2);
-                    const C A = cx_add_conj<T>(z, m), B = cx_sub_conj<T>(z, m);
-                    const C Tw = cx_mul<T>(B, ow[r][k2]);
-                    pw[(r * (CL / 2) + k2) * 2] = cx_norm<T>(A + Tw);
-                    pw[(r * (CL / 2) + k2) * 2 + 1] = cx_norm<T>(A - Tw);
-                }
+            for (int h = 0; h < 4; ++h) {
+                constexpr int H = CL / 2;
+                const int ra = h / H, ka = h % H, rb = (h + 4) / H, kb = (h + 4) % H;
+                const C za = zr[ra][r256_slot<CL>(ka)], zb = zr[rb][r256_slot<CL>(kb)];
+                const C ma = partner(ra, ka), mb = partner(rb, kb);
+                const C Aa = cx_add_conj<T>(za, ma), Ab = cx_add_conj<T>(zb, mb);
+                const C Ba = cx_sub_conj<T>(za, ma), Bb = cx_sub_conj<T>(zb, mb);
+                const C ta = cx_mul_first<T>(Ba, ow[ra][ka]), tb = cx_mul_first<T>(Bb, ow[rb][kb]);
+                const C Ta = cx_mul_second<T>(Ba, ow[ra][ka], ta), Tb = cx_mul_second<T>(Bb, ow[rb][kb], tb);
+                const C rea = cx_fma(C{Ta.x, Ta.x}, pm, C{Aa.x, Aa.x}), reb = cx_fma(C{Tb.x, Tb.x}, pm, C{Ab.x, Ab.x});
+                const C ima = cx_fma(C{Ta.y, Ta.y}, pm, C{Aa.y, Aa.y}), imb = cx_fma(C{Tb.y, Tb.y}, pm, C{Ab.y, Ab.y});
+                const C qa = rea * rea, qb = reb * reb;
+                const C sa = ima * ima, sb = imb * imb;
+                const C pa = qa + sa, pb = qb + sb;
+                pw[2 * h] = pa.x; pw[2 * h + 1] = pa.y;
+                pw[2 * (h + 4)] = pb.x; pw[2 * (h + 4) + 1] = pb.y;
             }
             if (EPI) {
                 power_epilogue_n(pw, a.epi);

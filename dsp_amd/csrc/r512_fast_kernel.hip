@@ -78,6 +78,9 @@ template <> struct vec16u<float> { typedef float type __attribute__((ext_vector_
 template <> struct vec16u<double> { typedef double type __attribute__((ext_vector_type(2), aligned(8))); };
 
 #ifndef R512F_TW_LDS
+#ifndef R512F_SPLIT_PAIRS
+#define R512F_SPLIT_PAIRS 1     // 1: the real-FFT split handles two bins at a time with packed norms (see there)
+#endif
 #ifndef R512F_GLDS_SPLIT
 #define R512F_GLDS_SPLIT 1      // 1: the span's LDS-DMA loads take their addresses as scalar base + 32-bit lane offset (ring_glds16_at)
 #endif
@@ -373,11 +376,11 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
         nsid = first + (t >> 3) * round + (t & 7);
         more = nsid < s_hi;
         if (more) {
-            const int nq = (int)a.spd.div((unsigned)nsid);
-            const int nb = ILV ? nsid - nq * a.sps : nq;
-            nw = ILV ? nq : (nsid - nb * a.sps) * 4;
-            nxb = ILV ? X + 4 * nb : X + (long long)nb * a.ldx;
-            nyb = Y + (long long)(ILV ? 4 * nb : nb) * a.Wy * ROWF;
+            const unsigned nq = a.spd.div((unsigned)nsid);                 // (unsigned: the products below stay short)
+            const unsigned nb = ILV ? (unsigned)nsid - nq * (unsigned)a.sps : nq;
+            nw = ILV ? (int)nq : (nsid - (int)nb * a.sps) * 4;
+            nxb = ILV ? X + 4 * nb : X + (unsigned long long)nb * (unsigned long long)a.ldx;
+            nyb = Y + (unsigned long long)(ILV ? 4 * nb : nb) * ((unsigned long long)a.Wy * ROWF);
         }
     };
 
@@ -563,19 +566,46 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
         } else {
             T pw[16];                                          // pw[k2] = P[k], pw[8 + k2] = P[256 - k]
             T p128 = T(4) * cx_norm<T>(zz[slot16(8)]);         // lane j == 0 only
+            // (lane 0 is its own partner: the move hands it its own register 15 - k2, which the select replaces; a
+            // select in front of the move would be turned into a select of the register INDEX, a 16-way chain)
+            auto partner = [&](const int k2) __attribute__((always_inline)) {
+                const C own = zz[slot16((16 - k2) & 15)], oth = zz[slot16(15 - k2)];
+                const T px = dpp_partner16(oth.x), py = dpp_partner16(oth.y);
+                return C{(j == 0) ? own.x : px, (j == 0) ? own.y : py};
+            };
+#if R512F_SPLIT_PAIRS
+            // two bins at a time, stage by stage (a packed instruction that consumes the result of the one issued just before it
+            // costs a wait state, and the stages of one bin are such a chain); (|A + T|^2, |A - T|^2) as one pair: the real parts
+            // of both sums in one packed register, the imaginary parts in another (x * 1 + y is x + y exactly)
+            const C pm = C{T(1), T(-1)};
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int ka = h, kb = h + 4;
+                const C za = zz[slot16(ka)], zb = zz[slot16(kb)];
+                const C ma = partner(ka), mb = partner(kb);
+                const C Aa = cx_add_conj<T>(za, ma), Ab = cx_add_conj<T>(zb, mb);
+                const C Ba = cx_sub_conj<T>(za, ma), Bb = cx_sub_conj<T>(zb, mb);
+                const C ta = cx_mul_first<T>(Ba, ow[ka]), tb = cx_mul_first<T>(Bb, ow[kb]);
+                const C Ta = cx_mul_second<T>(Ba, ow[ka], ta), Tb = cx_mul_second<T>(Bb, ow[kb], tb);
+                const C rea = cx_fma(C{Ta.x, Ta.x}, pm, C{Aa.x, Aa.x}), reb = cx_fma(C{Tb.x, Tb.x}, pm, C{Ab.x, Ab.x});
+                const C ima = cx_fma(C{Ta.y, Ta.y}, pm, C{Aa.y, Aa.y}), imb = cx_fma(C{Tb.y, Tb.y}, pm, C{Ab.y, Ab.y});
+                const C qa = rea * rea, qb = reb * reb;
+                const C sa = ima * ima, sb = imb * imb;
+                const C pa = qa + sa, pb = qb + sb;
+                pw[ka] = pa.x; pw[8 + ka] = pa.y;
+                pw[kb] = pb.x; pw[8 + kb] = pb.y;
+            }
+#else
 #pragma unroll
             for (int k2 = 0; k2 < 8; ++k2) {
                 const C z = zz[slot16(k2)];
-                // (lane 0 is its own partner: the move hands it its own register 15 - k2, which the select replaces; a
-                // select in front of the move would be turned into a select of the register INDEX, a 16-way chain)
-                const C own = zz[slot16((16 - k2) & 15)], oth = zz[slot16(15 - k2)];
-                const T px = dpp_partner16(oth.x), py = dpp_partner16(oth.y);
-                const C m = C{(j == 0) ? own.x : px, (j == 0) ? own.y : py};
+                const C m = partner(k2);
                 const C A = cx_add_conj<T>(z, m), B = cx_sub_conj<T>(z, m);
                 const C Tw = cx_mul<T>(B, ow[k2]);
                 pw[k2] = cx_norm<T>(A + Tw);
                 pw[8 + k2] = cx_norm<T>(A - Tw);
             }
+#endif
             if (EPI) {
                 power_epilogue_n(pw, a.epi);
                 p128 = power_epilogue(p128, a.epi);

@@ -55,6 +55,13 @@ template <typename T> __host__ __device__ constexpr int r512x_waves() { return s
 #ifndef R512X_TWD_LDS
 #define R512X_TWD_LDS (sizeof(T) == 4 && (Q == 4 || (SPAN == 2048 && !RQ)))   // where the pass-1 twiddles of the 256-point transform come from an LDS table instead of 30 registers (these instantiations spill otherwise; measured: 1024 / hop 512 0.480 -> 0.449 ms, and 6 % slower where nothing spills)
 #endif
+#ifndef R512X_WIN_LDS
+#define R512X_WIN_LDS (sizeof(T) == 8 && Q == 2)   // the halved window taps of the input stage come from an LDS table instead of 16 register pairs: in float64
+                                         // they are 64 registers of the 300 the kernel wants, and what does not fit the 256 vector registers lives in
+                                         // accumulation registers at one copy per use (93 copies per step of the 1024-point kernel; nfft 1024 float64
+                                         // 0.926 -> 0.898 ms; with the input stage's twiddles in the table as well 0.913; nfft 2048, Q = 4, measured 0.7 % slower with
+                                         // it and keeps its registers)
+#endif
 #ifndef R512X_TWD_AHEAD
 #define R512X_TWD_AHEAD 1       // 1: the LDS twiddles of a step are read in one go before the pass-1 transform
 #endif
@@ -232,7 +239,10 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
     pair_a *ex = reinterpret_cast<pair_a *>(xs);
     T *slot = xs + R512X_TILE;                                         // the span
     pair_a *ttab = reinterpret_cast<pair_a *>(reinterpret_cast<T *>(smem_raw) + NWV * WAVE_LDS);   // W256^(j k1) at [k1][j]
-    unsigned char *dummy = reinterpret_cast<unsigned char *>(ttab + (R512X_TWD_LDS ? 256 : 0));   // 1 KiB that placeholder LDS-DMA loads write
+    constexpr int WLN = 16 * Q;                                         // lanes of a frame
+    pair_a *wtab = ttab + (R512X_TWD_LDS ? 256 : 0);                    // window taps of lane l of a frame, pair e: [e][l]
+    constexpr int WTE = 16;                                             // its pairs per lane
+    unsigned char *dummy = reinterpret_cast<unsigned char *>(wtab + (R512X_WIN_LDS ? WTE * WLN : 0));   // 1 KiB that placeholder LDS-DMA loads write
     unsigned *ticket = reinterpret_cast<unsigned *>(dummy + 1024);
 
     // ---- per-lane constants ----
@@ -262,6 +272,12 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
         }
 #pragma unroll
         for (int rr = 1; rr < Q; ++rr) { dt[(Q - 1) * i + rr - 1] = twn((2 * m * rr) & (NFFT - 1)); }
+    }
+    if constexpr (R512X_WIN_LDS) {
+        if (tid < WLN) {                                   // (the lanes of frame 0 of wave 0)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { wtab[e * WLN + tid] = pair_a{hw[e].x, hw[e].y}; }
+        }
     }
     C ow[8];                                               // -i W_nfft^K, K = Q (j + 16 k2) + r
 #pragma unroll
@@ -353,6 +369,12 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
         if (!RQ || t + 1 >= ulen) { ring_draw(drawn, cnt_addr); }
         // The span of this step was asked for in the middle of the last one; memory operations complete in issue
         // order and behind its NV loads lie that step's 5 row stores, which stay in flight.
+        // (window taps from the LDS table: asked for ahead of the wait)
+        [[maybe_unused]] C hwl[WTE];
+        if constexpr (R512X_WIN_LDS) {
+#pragma unroll
+            for (int e = 0; e < WTE; ++e) { const pair_a t = wtab[e * WLN + (lane & (WLN - 1))]; hwl[e] = C{t.x, t.y}; }
+        }
         if (first_step) { ring_wait_vm<0>(); } else { ring_wait_vm<NSTORE>(); }
         first_step = false;
         wave_sync();
@@ -388,7 +410,8 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
                         v.x = (32 * Q * i + 512 * q < lim) ? v.x : T(0);
                         v.y = (32 * Q * i + 512 * q + 1 < lim) ? v.y : T(0);
                     }
-                    A[Q * i + q] = v * hw[Q * i + q];
+                    if constexpr (R512X_WIN_LDS) { A[Q * i + q] = v * hwl[Q * i + q]; }
+                    else { A[Q * i + q] = v * hw[Q * i + q]; }
                 }
             }
             if (MN0) {
@@ -720,7 +743,7 @@ template <typename T, int Q, bool FULL, bool MN0, bool EPI, int SPAN, bool ALN, 
 static hipError_t launch_r512x_inst(T *Y, const T *X, const T *win, const T *tw, const R512XArgs &a, hipStream_t s)
 {
     constexpr int NWV = r512x_waves<T>();
-    const size_t lds = ((size_t)NWV * (R512X_TILE + SPAN) + (R512X_TWD_LDS ? 512 : 0)) * sizeof(T) + 1024 + 16;
+    const size_t lds = ((size_t)NWV * (R512X_TILE + SPAN) + (R512X_TWD_LDS ? 512 : 0) + (R512X_WIN_LDS ? 2 * 16 * 16 * Q : 0)) * sizeof(T) + 1024 + 16;
     static LdsGrant grant;
     if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r512x_kernel<T, Q, FULL, MN0, EPI, SPAN, ALN, CPLX, RQ>), lds, grant); e != hipSuccess) { return e; }
     long long grid = ((long long)a.steps + NWV - 1) / NWV;

@@ -148,9 +148,10 @@ __global__ __launch_bounds__(64 * r256_waves<T>(), sizeof(T) == 4 ? 2 : 1) void 
         if (idx >= M) { idx -= M; sg = T(-1); }
         twd[k1] = C{sg * tw[2 * idx], sg * tw[2 * idx + 1]};
     }
-    C hw[NR];                                              // halved window taps of the lane's column
+    constexpr int NRW = NR > 16 ? 16 : NR;                 // rows that hold data (NR = 17: all 16, and the window covers them: L = nfft)
+    C hw[NRW];                                             // halved window taps of the lane's column
 #pragma unroll
-    for (int n1 = 0; n1 < NR; ++n1) {
+    for (int n1 = 0; n1 < NRW; ++n1) {
         const int l = 2 * CL * n1 + 2 * j;
         hw[n1] = C{(l < L) ? T(0.5) * win[l] : T(0), (l + 1 < L) ? T(0.5) * win[l + 1] : T(0)};
     }
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(64 * r256_waves<T>(), sizeof(T) == 4 ? 2 : 1) void 
     __syncthreads();
 
     const int reach = a.tbl ? a.reach : (FPS - 1) * a.stp;
-    const int need = reach + min(L, 2 * CL * NR);             // samples of a span that pass 1 uses
+    const int need = reach + min(L, 2 * CL * NRW);             // samples of a span that pass 1 uses
     const T *xrow = slot + f * a.stp + 2 * j;
     // Start of the span of the step at frame w_ (wave-uniform).  Table form: the starts of the step's frames by
     // scalar loads (a vector load would put the compiler's own wait for ALL outstanding memory operations, the row
@@ -245,11 +246,11 @@ __global__ __launch_bounds__(64 * r256_waves<T>(), sizeof(T) == 4 ? 2 : 1) void 
         if constexpr (DSP_MASK_RECOMPUTE && NR == 16) { asm volatile("" : "+v"(lim)); }
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
-            if (n1 < NR) {
+            if (n1 < NRW) {
                 C v;
                 if constexpr (ALN) { const pair_a t = *reinterpret_cast<const pair_a *>(xrow + 2 * CL * n1); v = C{t.x, t.y}; }
                 else { const pair_u t = *reinterpret_cast<const pair_u *>(xrow + 2 * CL * n1); v = C{t.x, t.y}; }
-                if (NR == 16 || n1 == NR - 1) {            // rows that may reach past the window: keep that data out (0 * NaN)
+                if (NR == 16 || (NR < 16 && n1 == NR - 1)) {   // rows that may reach past the window: keep that data out (0 * NaN)
                     v.x = (2 * CL * n1 < lim) ? v.x : T(0);
                     v.y = (2 * CL * n1 + 1 < lim) ? v.y : T(0);
                 }
@@ -261,21 +262,21 @@ __global__ __launch_bounds__(64 * r256_waves<T>(), sizeof(T) == 4 ? 2 : 1) void 
         if (MN0) {
             C acc = zz[0];
 #pragma unroll
-            for (int n1 = 1; n1 < NR; ++n1) { acc += zz[n1]; }
+            for (int n1 = 1; n1 < NRW; ++n1) { acc += zz[n1]; }
             T sum = acc.x + acc.y;
 #pragma unroll
             for (int m = 1; m < CL; m *= 2) { sum += __shfl_xor(sum, m); }
             const T mean = sum / (T)L;
 #pragma unroll
-            for (int n1 = 0; n1 < NR; ++n1) {
-                if (NR == 16 || n1 == NR - 1) {
+            for (int n1 = 0; n1 < NRW; ++n1) {
+                if (NR == 16 || (NR < 16 && n1 == NR - 1)) {
                     zz[n1] -= C{(2 * CL * n1 < lim) ? mean : T(0), (2 * CL * n1 + 1 < lim) ? mean : T(0)};
                 } else {
                     zz[n1] -= C{mean, mean};
                 }
             }
         }
-        dft16x<T, NR>(zz);
+        dft16x<T, NRW>(zz);
         wave_sync();                                       // all lanes have read the span
         // The slot takes the next step's span.  The reads of pass 1 must have RETURNED before the first load into
         // the slot is issued (the compiler may sink their consumers, and with them its own wait, below the
@@ -481,6 +482,15 @@ static hipError_t launch_r256_cl(T *Y, const T *X, const T *win, const T *tw, co
     }
     const int reach = (FPS - 1) * d.stp + NFFT;
     if (d.stp & 1) { return launch_r256_shape<T, CL, 16, MAXS, false>(Y, X, win, tw, a, d, cplx, s); }
+    // L = nfft (the window covers all 16 rows: no row of a lane is ever masked; the 32 lane masks of the general form live in scalar
+    // registers that spill into the lanes of a vector register)
+    if (d.L == NFFT) {
+        if (reach <= 1024) { return launch_r256_shape<T, CL, 17, 1024, true>(Y, X, win, tw, a, d, cplx, s); }
+        if constexpr (sizeof(T) == 4) {
+            if (reach <= 1280) { return launch_r256_shape<T, CL, 17, 1280, true>(Y, X, win, tw, a, d, cplx, s); }
+        }
+        return launch_r256_shape<T, CL, 17, MAXS, true>(Y, X, win, tw, a, d, cplx, s);
+    }
     if constexpr (sizeof(T) == 4) {
         // windows that leave the last three rows of pass 1 empty (nfft 256: 193 to 208 samples, 200 = 25 ms at 8 kHz)
         const bool nr13 = d.L > 12 * 2 * CL && d.L <= 13 * 2 * CL;

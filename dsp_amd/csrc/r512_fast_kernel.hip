@@ -212,10 +212,11 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
     C ow[8];                                               // -i W512^(j + 16 k2), k2 < 8
 #pragma unroll
     for (int k2 = 0; k2 < 8; ++k2) { ow[k2] = C{tw[2 * (j + 16 * k2) + 1], -tw[2 * (j + 16 * k2)]}; }
-    C hw[NR];                                              // halved window taps of this lane's columns
+    constexpr int NRW = NR > 16 ? 16 : NR;                 // rows of 32 that hold data (NR = 17: all 16, and the window covers them: L = 512)
+    C hw[NRW];                                             // halved window taps of this lane's columns
     if (WINREG) {
 #pragma unroll
-        for (int n1 = 0; n1 < NR; ++n1) {
+        for (int n1 = 0; n1 < NRW; ++n1) {
             const int l = 32 * n1 + 2 * j;
             hw[n1] = C{(l < L) ? T(0.5) * win[l] : T(0), (l + 1 < L) ? T(0.5) * win[l + 1] : T(0)};
         }
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
     const int lstp = a.stp - ((WIDE == 2 && !TBL) ? a.gap : 0);   // distance of a step's frames in the staged span
     const int reach = TBL ? a.stp : 3 * lstp;                // start of the step's last frame relative to its first
     const int need = reach + 512;
-    const int nvec = (reach + 32 * NR + VEC - 1) / VEC;      // 16-byte vectors of a span that pass 1 reads
+    const int nvec = (reach + 32 * NRW + VEC - 1) / VEC;      // 16-byte vectors of a span that pass 1 reads
     const T *xrow = ILV ? slot + 8 * j + f : (RING ? slot : xs) + f * lstp + 2 * j;   // (table form: set per step)
     // table form: lane i holds the start of frame w + (i & 3) of a step (clamped to the last frame)
     auto tbl_fetch = [&](const int w_) { return a.tbl[2 * min(w_ + (lane & 3), a.W - 1)]; };
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
         if constexpr (DSP_MASK_RECOMPUTE && NR == 16) { asm volatile("" : "+v"(lim)); }
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
-            if (n1 < NR) {
+            if (n1 < NRW) {
                 C v;
                 if constexpr (ILV) {
                     v = C{xrow[128 * n1], xrow[128 * n1 + 4]};
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
                     const T2 t = *reinterpret_cast<const T2 *>(xrow + 32 * n1);
                     v = C{t.x, t.y};
                 }
-                if (NR == 16 || n1 == NR - 1) {          // rows that may reach past the window
+                if (NR == 16 || (NR < 16 && n1 == NR - 1)) {   // rows that may reach past the window
                     v.x = (32 * n1 < lim) ? v.x : T(0);
                     v.y = (32 * n1 + 1 < lim) ? v.y : T(0);
                 }
@@ -464,21 +465,21 @@ __global__ __launch_bounds__(64 * R512F_WAVES, 2) void stft_r512_fast_kernel(T *
         if (MN0) {
             C acc = zz[0];
 #pragma unroll
-            for (int n1 = 1; n1 < NR; ++n1) { acc += zz[n1]; }
+            for (int n1 = 1; n1 < NRW; ++n1) { acc += zz[n1]; }
             T sum = acc.x + acc.y;
             sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2);
             sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8);
             const T mean = sum / T(L);
 #pragma unroll
-            for (int n1 = 0; n1 < NR; ++n1) {
-                if (NR == 16 || n1 == NR - 1) {          // rows that may reach past the window
+            for (int n1 = 0; n1 < NRW; ++n1) {
+                if (NR == 16 || (NR < 16 && n1 == NR - 1)) {   // rows that may reach past the window
                     zz[n1] -= C{(32 * n1 < lim) ? mean : T(0), (32 * n1 + 1 < lim) ? mean : T(0)};
                 } else {
                     zz[n1] -= C{mean, mean};
                 }
             }
         }
-        dft16x<T, NR>(zz);
+        dft16x<T, NRW>(zz);
         const T *nxrow = xrow;
         if constexpr (TBL && !RING) {
             if (more) { nxrow = tbl_xrow(tvn); load_span(nxb, __builtin_amdgcn_readfirstlane(tvn)); }
@@ -820,6 +821,16 @@ static hipError_t launch_stft_r512_fast_one(T *Y, const T *X, const T *win, cons
     if (3 * d.stp + 512 > 1280) {
         if (d.mn0) { return epi ? DSP_R512X(true, true) : DSP_R512X(true, false); }
         return epi ? DSP_R512X(false, true) : DSP_R512X(false, false);
+    }
+    // L = 512 (the window covers all 16 rows: no row of a lane is ever masked; the 32 lane masks of the general form live in scalar
+    // registers that spill into the lanes of a vector register, about 90 instructions per step)
+    if (d.L == 512 && wide) {
+        if (d.mn0) { return epi ? DSP_R512W(17, true, true) : DSP_R512W(17, true, false); }
+        return epi ? DSP_R512W(17, false, true) : DSP_R512W(17, false, false);
+    }
+    if (d.L == 512) {
+        if (d.mn0) { return epi ? DSP_R512F(17, true, true) : DSP_R512F(17, true, false); }
+        return epi ? DSP_R512F(17, false, true) : DSP_R512F(17, false, false);
     }
     if (wide && nr13) {
         if (d.mn0) { return epi ? DSP_R512W(13, true, true) : DSP_R512W(13, true, false); }

@@ -451,6 +451,38 @@ def test_both_4096_families_agree_with_oracle(O, D, dt):
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_full_window_instantiations(O, D, dt):
+    """L = nfft for nfft 64 ... 512: instantiations of the span-slot kernels without the lane masks of the rows that may reach past
+    the window.  Hops nfft/4 and nfft/2 (the aligned span forms), an odd hop (which keeps the general instantiation), every flag,
+    both framings, signals that end inside a step and shorter than the window; against the oracle, and bit for bit against the
+    general instantiation (selected by the same window without its last tap, which is zero in both)."""
+    import torch
+    for nfft in (64, 128, 256, 512):
+        win = D.hann(nfft, dt)
+        wd = torch.from_numpy(win).cuda()
+        for (B, N, snip, flags) in [(3, 40 * nfft + 13, 0, (0, 0, 0)), (2, 9 * nfft, 1, (1, 0, 0)), (1, nfft - 5, 0, (0, 1, 1)), (4, 17 * nfft + 1, 1, (1, 1, 1))]:
+            x = np.stack([signal(5 * b + N + nfft, N, dt) + dt(0.1) for b in range(B)])
+            xd = torch.from_numpy(x).cuda()
+            for hop in (nfft // 4, nfft // 2, nfft // 4 + 1):
+                if snip and N < nfft:
+                    continue
+                got = D.stft_dev(xd, wd, hop, bool(snip), *[bool(f) for f in flags], nfft=nfft).cpu().numpy()
+                for b in (0, B - 1):
+                    rc, Yref = O.stft(x[b].astype(np.float64), win.astype(np.float64), hop, nfft, snip, *flags, exact=False)
+                    assert rc == 0
+                    check_spec(O, got[b], Yref.astype(dt), flags[1], flags[2])
+        # the general instantiation on the same taps: a window whose last tap is zero, with and without that tap
+        wz = win.copy()
+        wz[-1] = 0
+        x = np.stack([signal(77 + b, 33 * nfft + 3, dt) for b in range(2)])
+        xd = torch.from_numpy(x).cuda()
+        # (frames from sample 0, so that the window length does not move them; N leaves both lengths the same number of frames)
+        full = D.stft_dev(xd, torch.from_numpy(wz).cuda(), nfft // 4, True, nfft=nfft)
+        gen = D.stft_dev(xd, torch.from_numpy(wz[:-1].copy()).cuda(), nfft // 4, True, nfft=nfft)
+        assert full.shape == gen.shape and torch.equal(full, gen), nfft
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
 def test_2048_ring_of_quarters(O, D, dt, monkeypatch):
     """nfft 2048 with a full window and hop 512 or 1024: large inputs are transformed in units of consecutive frames per wave, the
     span slot kept as a ring of four quarters of which only the new one is fetched per frame.  Forced here at small sizes

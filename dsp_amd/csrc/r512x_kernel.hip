@@ -55,6 +55,10 @@ template <typename T> __host__ __device__ constexpr int r512x_waves() { return s
 #ifndef R512X_TWD_LDS
 #define R512X_TWD_LDS (sizeof(T) == 4 && (Q == 4 || (SPAN == 2048 && !RQ)))   // where the pass-1 twiddles of the 256-point transform come from an LDS table instead of 30 registers (these instantiations spill otherwise; measured: 1024 / hop 512 0.480 -> 0.449 ms, and 6 % slower where nothing spills)
 #endif
+#ifndef R512X_ZERO_TAIL
+#define R512X_ZERO_TAIL 1       // 1: nfft 2048 (one frame per step, the slot its own) with a window shorter than the transform reads the slot
+                                // unmasked: what lies past the window in the slot is made harmless instead (see UNMASKED in the kernel)
+#endif
 #ifndef R512X_WIN_LDS
 #define R512X_WIN_LDS (sizeof(T) == 8 && Q == 2)   // the halved window taps of the input stage come from an LDS table instead of 16 register pairs: in float64
                                          // they are 64 registers of the 300 the kernel wants, and what does not fit the 256 vector registers lives in
@@ -226,6 +230,12 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
     constexpr bool DIRECT = R512X_DIRECT_STORE && !CPLX && !F32;
     constexpr int NSTORE = DIRECT ? 17 : F32 ? NVI + 1 : (FPS * ROWF + 63) / 64;   // store instructions per step
     static_assert(FPS * ROWF + 3 <= R512X_TILE, "row staging fits the tile");
+    // Windows shorter than the transform: the rows of a lane past the window must not reach the sums even as 0 x NaN.  The general way is a lane
+    // mask per row and element (32 of them, in scalar registers that spill).  With one frame per step the slot belongs to that frame alone, and
+    // it is cheaper to see to it that the slot holds nothing past the window that is not a sample of the window: the lanes past the last
+    // vector of the span copy the vector before it (ring_load_span<.., SPARE>), and the up to three samples behind the window inside the
+    // last vector are overwritten with zeros once the span has landed.  (Needs two vectors of window: r512x_supported.)
+    constexpr bool UNMASKED = R512X_ZERO_TAIL && Q == 4 && !FULL && !MN0 && !RQ;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -305,7 +315,7 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
     // ---- fetch of one span into the slot: NV LDS-DMA loads whatever the case (the counted wait relies on
     // that); a span that crosses an edge of its signal is gathered sample by sample and NV placeholder loads follow
     auto load_span = [&](const T *xb, const int s0) {
-        ring_load_span<NV>(slot, reinterpret_cast<T *>(dummy), tw, R512X_NOLOAD ? tw - (s0 - (a.edge ? a.rd_shift : 0)) : xb, s0, need, a.N, a.edge, a.rd_shift, lane,
+        ring_load_span<NV, UNMASKED>(slot, reinterpret_cast<T *>(dummy), tw, R512X_NOLOAD ? tw - (s0 - (a.edge ? a.rd_shift : 0)) : xb, s0, need, a.N, a.edge, a.rd_shift, lane,
                            [&](const T *sig, const int first, const int i) {
                                FrameDesc d{};
                                d.N = a.N; d.edge = a.edge;
@@ -377,6 +387,10 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
         }
         if (first_step) { ring_wait_vm<0>(); } else { ring_wait_vm<NSTORE>(); }
         first_step = false;
+        if constexpr (UNMASKED) {
+            constexpr int VEC = 16 / (int)sizeof(T);
+            if (lane < ((-L) & (VEC - 1))) { slot[L + lane] = T(0); }
+        }
         wave_sync();
         R512X_STAMP(0);                                    // wait for the span
 
@@ -406,7 +420,7 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
                     C v;
                     if constexpr (ALN) { const pair_a t = *reinterpret_cast<const pair_a *>(p); v = C{t.x, t.y}; }
                     else { const pair_u t = *reinterpret_cast<const pair_u *>(p); v = C{t.x, t.y}; }
-                    if (!FULL) {                           // keep data past the window out (0 * NaN)
+                    if (!FULL && !UNMASKED) {              // keep data past the window out (0 * NaN)
                         v.x = (32 * Q * i + 512 * q < lim) ? v.x : T(0);
                         v.y = (32 * Q * i + 512 * q + 1 < lim) ? v.y : T(0);
                     }
@@ -734,6 +748,7 @@ bool r512x_supported(const FrameDesc &d)
     // (tbl_reach bounds the distance of frames w and w + 3, hence that of the fps <= 2 frames of a step)
     const bool placed = d.tbl ? (d.tbl_reach >= 0 && (fps == 1 || d.tbl_reach + d.nfft <= 2048))
                               : (d.stp >= 1 && (long long)(fps - 1) * d.stp + d.nfft <= 2048);
+    if (R512X_ZERO_TAIL && d.nfft == 2048 && d.L < 8) { return false; }      // (the unmasked form needs two 16-byte vectors of window)
     return placed && d.L >= 1 && d.L <= d.nfft &&
            d.N < (1ll << 31) - 4096 && (long long)d.wy() * (d.nfft / 2 + 1) < (1ll << 30) && (long long)d.B * d.W < (1ll << 30) &&
            d.ss0 > -(1ll << 30) && d.ss0 < (1ll << 30) && d.rd_shift >= 0 && d.rd_shift < (1ll << 30);

@@ -122,7 +122,9 @@ __device__ __forceinline__ void ring_store_rows(float *__restrict__ yblk, const 
 // NV wave loads of 1 KiB, lanes past the last vector that is used (nvec = ceil(need / VEC), VEC = 16 bytes of samples)
 // read that vector again.  A span that crosses an edge of its signal is gathered sample by sample (reflection or zeros)
 // and NV placeholder loads follow, from the first KiB of `tw` into `dummy`.
-template <int NV, typename T, typename FETCH>
+// SPARE: the lanes past the last vector read the vector BEFORE it (all of whose samples are needed) instead: the copies that fill the
+// rest of the slot then hold nothing but samples of the span proper, for kernels that read the slot past `need` unmasked.
+template <int NV, bool SPARE = false, typename T, typename FETCH>
 __device__ __forceinline__ void ring_load_span(T *slot, T *dummy, const T *tw, const T *xb, const int s0, const int need,
                                                const int N, const int edge, const int rd_shift, const int lane, FETCH fetch)
 {
@@ -139,7 +141,9 @@ __device__ __forceinline__ void ring_load_span(T *slot, T *dummy, const T *tw, c
 #ifdef RING_FAKE_NV
             if (q >= RING_FAKE_NV) { continue; }       // diagnostic builds: fewer loads (wrong results)
 #endif
-            ring_glds16_at(src, min(1024u * q + 16u * lane, last), lds0, 1024 * q);
+            const unsigned own = 1024u * q + 16u * lane;
+            if constexpr (SPARE) { ring_glds16_at(src, own > last ? (last >= 16u ? last - 16u : last) : own, lds0, 1024 * q); }
+            else { ring_glds16_at(src, min(own, last), lds0, 1024 * q); }
         }
     } else {
 #pragma clang loop unroll(disable)

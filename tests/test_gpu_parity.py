@@ -1048,6 +1048,30 @@ def test_nan_stays_in_its_own_frames(O, D):
         check_spec(O, Y[ok], Yref[ok])
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_nan_behind_a_short_window_stays_out(O, D, dt):
+    """Windows shorter than the transform on the 1024- and 2048-point kernels (the latter reads its span slot unmasked and makes what
+    lies behind the window in the slot harmless instead): NaN and Inf samples reach exactly the frames whose window contains them,
+    for even and odd window lengths (the samples behind the window inside the last 16 bytes of a span) and frames at both edges."""
+    import torch
+    for nfft, L, hop in ((2048, 1102, 441), (2048, 1103, 441), (2048, 1201, 480), (2048, 9, 700), (1024, 551, 220), (1024, 800, 200)):
+        N = 40 * hop + L
+        x = signal(3 + L, N, dt)
+        bad = [0, L, L + 1, 5 * hop + L, 5 * hop + L + 1, 5 * hop + L + 2, 17 * hop - 1, N - 1]
+        for k, i in enumerate(bad):
+            x[i] = np.nan if k % 2 == 0 else np.inf
+        win = D.povey(L, dt)
+        for snip in (True, False):
+            rc, Yref = O.stft(x.astype(np.float64), win.astype(np.float64), hop, nfft, int(snip), 0, 0, 0, exact=False)
+            assert rc == 0
+            Y = D.stft_dev(torch.from_numpy(x[None]).cuda(), torch.from_numpy(win).cuda(), hop, snip, nfft=nfft)[0].cpu().numpy()
+            assert Y.shape == Yref.shape
+            finite_ref = np.isfinite(Yref).all(axis=1)
+            assert np.array_equal(np.isfinite(Y).all(axis=1), finite_ref), (nfft, L, hop, snip)
+            assert finite_ref.sum() > 10
+            check_spec(O, Y[finite_ref], Yref[finite_ref].astype(dt))
+
+
 def test_log_of_silence_is_minus_inf(D):
     Y = D.stft(np.zeros(4000, np.float32), D.hann(400), 160, lg=True)
     assert np.all(np.isneginf(Y))

@@ -121,6 +121,25 @@ __device__ __forceinline__ void dft4c(cx<T> &a0, cx<T> &a1, cx<T> &a2, cx<T> &a3
     a3 = cx_add_i<T>(s1, t);
 }
 
+// ... with only the first NIN inputs other than zero (NIN = 1 ... 4)
+template <typename T, int NIN>
+__device__ __forceinline__ void dft4c_in(cx<T> &a0, cx<T> &a1, cx<T> &a2, cx<T> &a3)
+{
+    static_assert(NIN >= 1 && NIN <= 4, "one to four inputs");
+    if constexpr (NIN >= 3) { dft4c<T, NIN == 3>(a0, a1, a2, a3); }
+    else if constexpr (NIN == 2) {
+        const cx<T> e = a0, o = a1;
+        a0 = e + o;
+        a2 = e - o;
+        a1 = cx_sub_i<T>(e, o);
+        a3 = cx_add_i<T>(e, o);
+    } else {
+        a1 = a0; a2 = a0; a3 = a0;
+    }
+}
+// the inputs of column k of a 16-point transform's first stage (rows k, k + 4, k + 8, k + 12) that lie below NZ
+constexpr int dft16_nin(int NZ, int k) { return NZ >= 12 + k + 1 ? 4 : NZ >= 8 + k + 1 ? 3 : NZ >= 4 + k + 1 ? 2 : 1; }
+
 // dft16 on pairs: same index map, same output slots, same known-zero rows
 template <typename T, int NZ = 16>
 __device__ __forceinline__ void dft16c(cx<T> (&z)[16])
@@ -236,11 +255,11 @@ __device__ __forceinline__ void dft4c_tw(cx<T> &a0, cx<T> &a1, cx<T> &a2, cx<T> 
 template <typename T, int NZ = 16>
 __device__ __forceinline__ void dft16f(cx<T> (&z)[16])
 {
-    static_assert(NZ >= 13 && NZ <= 16, "only the last row of each column may be known-zero");
-    dft4c<T, (NZ <= 12)>(z[0], z[4], z[8], z[12]);
-    dft4c<T, (NZ <= 13)>(z[1], z[5], z[9], z[13]);
-    dft4c<T, (NZ <= 14)>(z[2], z[6], z[10], z[14]);
-    dft4c<T, (NZ <= 15)>(z[3], z[7], z[11], z[15]);
+    static_assert(NZ >= 4 && NZ <= 16, "rows NZ and above are known to be zero; every column keeps its first row");
+    dft4c_in<T, dft16_nin(NZ, 0)>(z[0], z[4], z[8], z[12]);
+    dft4c_in<T, dft16_nin(NZ, 1)>(z[1], z[5], z[9], z[13]);
+    dft4c_in<T, dft16_nin(NZ, 2)>(z[2], z[6], z[10], z[14]);
+    dft4c_in<T, dft16_nin(NZ, 3)>(z[3], z[7], z[11], z[15]);
     // slot 4 k1 + n2 holds a[n2][k1]; row k1 takes the twiddles W16^(n2 k1)
     dft4c<T>(z[0], z[1], z[2], z[3]);
     dft4c_tw<T, 16, 1, 2, 3>(z[4], z[5], z[6], z[7]);

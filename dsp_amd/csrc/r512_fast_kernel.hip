@@ -832,6 +832,22 @@ static hipError_t launch_stft_r512_fast_one(T *Y, const T *X, const T *win, cons
         if (d.mn0) { return epi ? DSP_R512F(17, true, true) : DSP_R512F(17, true, false); }
         return epi ? DSP_R512F(17, false, true) : DSP_R512F(17, false, false);
     }
+    // other windows whose last rows are empty: 8 rows (225 to 256 samples), 10 (289 to 320: 20 ms at 16 kHz), 15 (449 to 480: 30 ms).  Only the last
+    // row of a lane that holds data is masked then, and the first stage of the 16-point transform skips the empty rows.
+    const int rows = (d.L + 31) / 32;
+#define DSP_R512ROWS(NR_)                                                                                       \
+    if (rows == NR_ && wide) {                                                                                  \
+        if (d.mn0) { return epi ? DSP_R512W(NR_, true, true) : DSP_R512W(NR_, true, false); }                   \
+        return epi ? DSP_R512W(NR_, false, true) : DSP_R512W(NR_, false, false);                                \
+    }                                                                                                           \
+    if (rows == NR_) {                                                                                          \
+        if (d.mn0) { return epi ? DSP_R512F(NR_, true, true) : DSP_R512F(NR_, true, false); }                   \
+        return epi ? DSP_R512F(NR_, false, true) : DSP_R512F(NR_, false, false);                                \
+    }
+    DSP_R512ROWS(8)
+    DSP_R512ROWS(10)
+    DSP_R512ROWS(15)
+#undef DSP_R512ROWS
     if (wide && nr13) {
         if (d.mn0) { return epi ? DSP_R512W(13, true, true) : DSP_R512W(13, true, false); }
         return epi ? DSP_R512W(13, false, true) : DSP_R512W(13, false, false);

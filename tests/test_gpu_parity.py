@@ -483,6 +483,30 @@ def test_full_window_instantiations(O, D, dt):
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_row_count_instantiations_of_the_512_point_kernel(O, D, dt):
+    """nfft 512 with windows of 8, 10, 13 and 15 rows of 32 samples (instantiations that skip the empty rows and mask only the last
+    one that holds data), at both ends of each range and just outside it; narrow, wide and odd hops; every flag; NaN behind the
+    window stays out."""
+    import torch
+    for L in (224, 225, 256, 257, 288, 289, 320, 321, 385, 416, 448, 449, 480, 481):
+        win = D.povey(L, dt)
+        wd = torch.from_numpy(win).cuda()
+        for (hop, N, snip, flags) in [(160, 40 * 160 + L, 0, (0, 0, 0)), (256, 9000, 1, (1, 0, 0)), (161, 7001, 0, (1, 1, 1)), (100, 5000, 1, (0, 1, 0))]:
+            x = np.stack([signal(L + b, N, dt) + dt(0.1) for b in range(3)])
+            got = D.stft_dev(torch.from_numpy(x).cuda(), wd, hop, bool(snip), *[bool(f) for f in flags], nfft=512).cpu().numpy()
+            for b in (0, 2):
+                rc, Yref = O.stft(x[b].astype(np.float64), win.astype(np.float64), hop, 512, snip, *flags, exact=False)
+                assert rc == 0
+                check_spec(O, got[b], Yref.astype(dt), flags[1], flags[2])
+        # a NaN right behind the window of frame 3 (snip_edges framing: frames start at w * hop)
+        x = signal(L, 30 * 160 + 512, dt)
+        x[3 * 160 + L] = np.nan
+        Y = D.stft_dev(torch.from_numpy(x[None]).cuda(), wd, 160, True, nfft=512)[0].cpu().numpy()
+        bad = np.isnan(Y).any(axis=1)
+        assert not bad[3] and bad[4] and bad.sum() == len([w for w in range(Y.shape[0]) if w * 160 <= 3 * 160 + L < w * 160 + L]), L
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
 def test_2048_ring_of_quarters(O, D, dt, monkeypatch):
     """nfft 2048 with a full window and hop 512 or 1024: large inputs are transformed in units of consecutive frames per wave, the
     span slot kept as a ring of four quarters of which only the new one is fetched per frame.  Forced here at small sizes

@@ -495,6 +495,12 @@ static hipError_t launch_r256_cl(T *Y, const T *X, const T *win, const T *tw, co
         // windows that leave the last three rows of pass 1 empty (nfft 256: 193 to 208 samples, 200 = 25 ms at 8 kHz)
         const bool nr13 = d.L > 12 * 2 * CL && d.L <= 13 * 2 * CL;
         if (reach <= 1024) {
+            if constexpr (CL == 8) {
+                // nfft 256: 10 rows (145 to 160 samples: 20 ms at 8 kHz) and 15 rows (225 to 240: 30 ms) likewise
+                const int rows = (d.L + 2 * CL - 1) / (2 * CL);
+                if (rows == 10) { return launch_r256_shape<T, CL, 10, 1024, true>(Y, X, win, tw, a, d, cplx, s); }
+                if (rows == 15) { return launch_r256_shape<T, CL, 15, 1024, true>(Y, X, win, tw, a, d, cplx, s); }
+            }
             return nr13 ? launch_r256_shape<T, CL, 13, 1024, true>(Y, X, win, tw, a, d, cplx, s)
                         : launch_r256_shape<T, CL, 16, 1024, true>(Y, X, win, tw, a, d, cplx, s);
         }

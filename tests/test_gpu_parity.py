@@ -506,6 +506,28 @@ def test_row_count_instantiations_of_the_512_point_kernel(O, D, dt):
         assert not bad[3] and bad[4] and bad.sum() == len([w for w in range(Y.shape[0]) if w * 160 <= 3 * 160 + L < w * 160 + L]), L
 
 
+def test_row_count_instantiations_of_the_256_point_kernel(O, D):
+    """nfft 256, float32, windows of 10, 13 and 15 rows of 16 samples, at both ends of each range and just outside it; NaN behind the
+    window stays out."""
+    import torch
+    dt = np.float32
+    for L in (144, 145, 160, 161, 193, 208, 224, 225, 240, 241):
+        win = D.povey(L, dt)
+        wd = torch.from_numpy(win).cuda()
+        for (hop, N, snip, flags) in [(80, 60 * 80 + L, 0, (0, 0, 0)), (64, 5000, 1, (1, 1, 0)), (81, 4001, 0, (1, 0, 1))]:
+            x = np.stack([signal(L + b, N, dt) + dt(0.1) for b in range(3)])
+            got = D.stft_dev(torch.from_numpy(x).cuda(), wd, hop, bool(snip), *[bool(f) for f in flags], nfft=256).cpu().numpy()
+            for b in (0, 2):
+                rc, Yref = O.stft(x[b], win, hop, 256, snip, *flags)
+                assert rc == 0
+                check_spec(O, got[b], Yref, flags[1], flags[2])
+        x = signal(L, 60 * 80 + 256, dt)
+        x[5 * 80 + L] = np.nan
+        Y = D.stft_dev(torch.from_numpy(x[None]).cuda(), wd, 80, True, nfft=256)[0].cpu().numpy()
+        bad = np.isnan(Y).any(axis=1)
+        assert not bad[5] and bad[6] and bad.sum() == len([w for w in range(Y.shape[0]) if w * 80 <= 5 * 80 + L < w * 80 + L]), L
+
+
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 def test_2048_ring_of_quarters(O, D, dt, monkeypatch):
     """nfft 2048 with a full window and hop 512 or 1024: large inputs are transformed in units of consecutive frames per wave, the

@@ -832,7 +832,7 @@ static hipError_t launch_stft_r512_fast_one(T *Y, const T *X, const T *win, cons
         if (d.mn0) { return epi ? DSP_R512F(17, true, true) : DSP_R512F(17, true, false); }
         return epi ? DSP_R512F(17, false, true) : DSP_R512F(17, false, false);
     }
-    // other windows whose last rows are empty: 8 rows (225 to 256 samples), 10 (289 to 320: 20 ms at 16 kHz), 15 (449 to 480: 30 ms).  Only the last
+    // other windows whose last rows are empty: 8 rows (225 to 256 samples), 10 (289 to 320: 20 ms at 16 kHz), 15 (449 to 480: 30 ms), and below the rest from 9 to 14.  Only the last
     // row of a lane that holds data is masked then, and the first stage of the 16-point transform skips the empty rows.
     const int rows = (d.L + 31) / 32;
 #define DSP_R512ROWS(NR_)                                                                                       \
@@ -847,6 +847,17 @@ static hipError_t launch_stft_r512_fast_one(T *Y, const T *X, const T *win, cons
     DSP_R512ROWS(8)
     DSP_R512ROWS(10)
     DSP_R512ROWS(15)
+#undef DSP_R512ROWS
+    // (the row counts in between, without mean removal)
+#define DSP_R512ROWS(NR_)                                                                                       \
+    if (rows == NR_ && !d.mn0) {                                                                                \
+        if (wide) { return epi ? DSP_R512W(NR_, false, true) : DSP_R512W(NR_, false, false); }                  \
+        return epi ? DSP_R512F(NR_, false, true) : DSP_R512F(NR_, false, false);                                \
+    }
+    DSP_R512ROWS(9)
+    DSP_R512ROWS(11)
+    DSP_R512ROWS(12)
+    DSP_R512ROWS(14)
 #undef DSP_R512ROWS
     if (wide && nr13) {
         if (d.mn0) { return epi ? DSP_R512W(13, true, true) : DSP_R512W(13, true, false); }

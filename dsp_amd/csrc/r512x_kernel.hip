@@ -207,7 +207,7 @@ constexpr int R512X_UNIT = R512X_UNIT_FRAMES;   // steps per unit
                                 // float32 and 1.055 -> 1.08 ms in float64 (units of 4, 6 or 12 steps alike): the step form fetches 5 loads per step
                                 // there, the ring 3 on average, and pays for them with a per-lane choice of block and a slot of 2048 samples
 #endif
-template <typename T, int Q, bool FULL, bool MN0, bool EPI, int SPAN, bool ALN, bool CPLX = false, bool RQ = false>
+template <typename T, int Q, bool FULL, bool MN0, bool EPI, int SPAN, bool ALN, bool CPLX = false, bool RQ = false, int NK = 16>
 __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void stft_r512x_kernel(T *__restrict__ Y, const T *__restrict__ X,
                                                                                                const T *__restrict__ win, const T *__restrict__ tw,
                                                                                                const R512XArgs a)
@@ -236,6 +236,11 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
     // vector of the span copy the vector before it (ring_load_span<.., SPARE>), and the up to three samples behind the window inside the
     // last vector are overwritten with zeros once the span has landed.  (Needs two vectors of window: r512x_supported.)
     constexpr bool UNMASKED = R512X_ZERO_TAIL && Q == 4 && !FULL && !MN0 && !RQ;
+    // nfft 1024 (two frames share a slot: nothing to be made harmless there) has instantiations by the number NK of the lane's rows of 64 samples
+    // that hold data instead (NK = ceil(L / 64) < 16: row k of a lane is the samples 64 k + 2 j + 32 g + {0, 1} of the frame, so rows below NK - 1 lie
+    // inside the window for every lane, row NK - 1 is masked, the rows above are zero and are not read).  NK = 16: the general form.
+    static_assert(NK == 16 || (Q == 2 && !FULL && !MN0 && !RQ), "row-count instantiations: nfft 1024, a window shorter than the transform, no mean removal");
+    constexpr bool ROWS = NK < 16;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -414,13 +419,14 @@ __global__ __launch_bounds__(64 * r512x_waves<T>(), sizeof(T) == 4 ? 2 : 1) void
             for (int i = 0; i < R; ++i) {
 #pragma unroll
                 for (int q = 0; q < Q; ++q) {
+                    if constexpr (ROWS) { if (i + 8 * q >= NK) { A[Q * i + q] = C{T(0), T(0)}; continue; } }
                     const T *p;
                     if constexpr (RQ && Q == 2) { p = (i < 4 ? rq_lo[q] : rq_hi[q]) + 32 * Q * i; }
                     else { p = xrow + 32 * Q * i + 512 * (RQ ? ((q + qstep * t) & 3) : q); }
                     C v;
                     if constexpr (ALN) { const pair_a t = *reinterpret_cast<const pair_a *>(p); v = C{t.x, t.y}; }
                     else { const pair_u t = *reinterpret_cast<const pair_u *>(p); v = C{t.x, t.y}; }
-                    if (!FULL && !UNMASKED) {              // keep data past the window out (0 * NaN)
+                    if (!FULL && !UNMASKED && (!ROWS || i + 8 * q == NK - 1)) {   // keep data past the window out (0 * NaN)
                         v.x = (32 * Q * i + 512 * q < lim) ? v.x : T(0);
                         v.y = (32 * Q * i + 512 * q + 1 < lim) ? v.y : T(0);
                     }
@@ -754,17 +760,17 @@ bool r512x_supported(const FrameDesc &d)
            d.ss0 > -(1ll << 30) && d.ss0 < (1ll << 30) && d.rd_shift >= 0 && d.rd_shift < (1ll << 30);
 }
 
-template <typename T, int Q, bool FULL, bool MN0, bool EPI, int SPAN, bool ALN, bool CPLX = false, bool RQ = false>
+template <typename T, int Q, bool FULL, bool MN0, bool EPI, int SPAN, bool ALN, bool CPLX = false, bool RQ = false, int NK = 16>
 static hipError_t launch_r512x_inst(T *Y, const T *X, const T *win, const T *tw, const R512XArgs &a, hipStream_t s)
 {
     constexpr int NWV = r512x_waves<T>();
     const size_t lds = ((size_t)NWV * (R512X_TILE + SPAN) + (R512X_TWD_LDS ? 512 : 0) + (R512X_WIN_LDS ? 2 * 16 * 16 * Q : 0)) * sizeof(T) + 1024 + 16;
     static LdsGrant grant;
-    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r512x_kernel<T, Q, FULL, MN0, EPI, SPAN, ALN, CPLX, RQ>), lds, grant); e != hipSuccess) { return e; }
+    if (hipError_t e = ensure_lds(reinterpret_cast<const void *>(&stft_r512x_kernel<T, Q, FULL, MN0, EPI, SPAN, ALN, CPLX, RQ, NK>), lds, grant); e != hipSuccess) { return e; }
     long long grid = ((long long)a.steps + NWV - 1) / NWV;
     if (grid > 256) { grid = 256; }                     // one workgroup per CU
     grid = (grid + 7) & ~7ll;                           // whole groups of 8 workgroups (one per XCD)
-    hipLaunchKernelGGL((stft_r512x_kernel<T, Q, FULL, MN0, EPI, SPAN, ALN, CPLX, RQ>), dim3((unsigned)grid), dim3(64 * NWV), lds, s, Y, X, win, tw, a);
+    hipLaunchKernelGGL((stft_r512x_kernel<T, Q, FULL, MN0, EPI, SPAN, ALN, CPLX, RQ, NK>), dim3((unsigned)grid), dim3(64 * NWV), lds, s, Y, X, win, tw, a);
     return hipGetLastError();
 }
 
@@ -815,6 +821,15 @@ static hipError_t launch_r512x_shape(T *Y, const T *X, const T *win, const T *tw
         return epi ? DSP_R512X(true, false, true) : DSP_R512X(true, false, false);
     }
     if (d.mn0) { return epi ? DSP_R512X(false, true, true) : DSP_R512X(false, true, false); }
+    if constexpr (Q == 2 && sizeof(T) == 4 && ALN) {
+        // windows of 8 to 15 rows of 64 samples (449 to 960 samples; 513-576: 25 ms at 22.05 kHz; 769-832: 25 ms at 32 kHz; 833-896: 20 ms at
+        // 44.1 kHz; 897-960: 20 ms at 48 kHz): one masked row instead of 32 lane masks
+        const int nk = (d.L + 63) / 64;
+#define DSP_R512XK(NK_) if (nk == NK_) { return epi ? launch_r512x_inst<T, Q, false, false, true, SPAN, ALN, false, false, NK_>(Y, X, win, tw, a, s)  \
+                                                    : launch_r512x_inst<T, Q, false, false, false, SPAN, ALN, false, false, NK_>(Y, X, win, tw, a, s); }
+        DSP_R512XK(8) DSP_R512XK(9) DSP_R512XK(10) DSP_R512XK(11) DSP_R512XK(12) DSP_R512XK(13) DSP_R512XK(14) DSP_R512XK(15)
+#undef DSP_R512XK
+    }
     return epi ? DSP_R512X(false, false, true) : DSP_R512X(false, false, false);
 #endif
 #undef DSP_R512X

@@ -484,11 +484,11 @@ def test_full_window_instantiations(O, D, dt):
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])
 def test_row_count_instantiations_of_the_512_point_kernel(O, D, dt):
-    """nfft 512 with windows of 8, 10, 13 and 15 rows of 32 samples (instantiations that skip the empty rows and mask only the last
-    one that holds data), at both ends of each range and just outside it; narrow, wide and odd hops; every flag; NaN behind the
+    """nfft 512 with windows of 8 to 15 rows of 32 samples (instantiations that skip the empty rows and mask only the last one that
+    holds data), at the ends of the ranges and just outside them; narrow, wide and odd hops; every flag; NaN behind the
     window stays out."""
     import torch
-    for L in (224, 225, 256, 257, 288, 289, 320, 321, 385, 416, 448, 449, 480, 481):
+    for L in (224, 225, 256, 257, 288, 289, 320, 321, 352, 353, 384, 385, 416, 417, 448, 449, 480, 481):
         win = D.povey(L, dt)
         wd = torch.from_numpy(win).cuda()
         for (hop, N, snip, flags) in [(160, 40 * 160 + L, 0, (0, 0, 0)), (256, 9000, 1, (1, 0, 0)), (161, 7001, 0, (1, 1, 1)), (100, 5000, 1, (0, 1, 0))]:
@@ -526,6 +526,31 @@ def test_row_count_instantiations_of_the_256_point_kernel(O, D):
         Y = D.stft_dev(torch.from_numpy(x[None]).cuda(), wd, 80, True, nfft=256)[0].cpu().numpy()
         bad = np.isnan(Y).any(axis=1)
         assert not bad[5] and bad[6] and bad.sum() == len([w for w in range(Y.shape[0]) if w * 80 <= 5 * 80 + L < w * 80 + L]), L
+
+
+def test_row_count_instantiations_of_the_1024_point_kernel(O, D):
+    """nfft 1024, float32, windows of 8 to 15 rows of 64 samples (one masked row, the rows above it not read), at the ends of the
+    ranges and just outside them; the 1280- and 2048-sample span forms, an odd hop (general instantiation), compression flags;
+    NaN and Inf behind the window of either frame of a step stay out."""
+    import torch
+    dt = np.float32
+    for L in (448, 449, 512, 513, 551, 576, 577, 640, 700, 768, 769, 800, 832, 833, 882, 896, 897, 960, 961):
+        win = D.povey(L, dt)
+        wd = torch.from_numpy(win).cuda()
+        for (hop, N, snip, flags) in [(220, 30 * 220 + L, 0, (0, 0, 0)), (256, 9000, 1, (0, 1, 0)), (400, 12001, 0, (0, 1, 1)), (221, 8000, 1, (0, 0, 0))]:
+            x = np.stack([signal(L + b, N, dt) + dt(0.1) for b in range(3)])
+            got = D.stft_dev(torch.from_numpy(x).cuda(), wd, hop, bool(snip), *[bool(f) for f in flags], nfft=1024).cpu().numpy()
+            for b in (0, 2):
+                rc, Yref = O.stft(x[b], win, hop, 1024, snip, *flags)
+                assert rc == 0
+                check_spec(O, got[b], Yref, flags[1], flags[2])
+        x = signal(L, 40 * 220 + 1024, dt)
+        x[4 * 220 + L] = np.nan            # right behind the window of frame 4 (the first frame of its step)
+        x[11 * 220 + L + 1] = np.inf       # ... and one sample further behind frame 11 (the second frame of its step)
+        Y = D.stft_dev(torch.from_numpy(x[None]).cuda(), wd, 220, True, nfft=1024)[0].cpu().numpy()
+        bad = ~np.isfinite(Y).all(axis=1)
+        want = np.array([any(w * 220 <= i < w * 220 + L for i in (4 * 220 + L, 11 * 220 + L + 1)) for w in range(Y.shape[0])])
+        assert np.array_equal(bad, want), L
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.float64])

@@ -720,6 +720,10 @@ extern "C" int dsp_debug_read_stamps(unsigned long long *dst, size_t n)
 }
 #endif
 
+#ifndef R512F_ROWS_TU
+#define R512F_ROWS_TU 0         // 1: this file compiled as r512_fast_rows.hip, the translation unit of the row-count instantiations
+#endif
+#if !R512F_ROWS_TU
 // Conditions of the fast path: frames at ss0 + w*hop with 3*hop + 512 <= 2048, or a table of frame starts
 // that never decrease, are read where they start and put frames w and w + 3 at most 1536 samples apart;
 // and every index of one signal's input and output fits 31 bits.
@@ -732,6 +736,7 @@ bool r512_fast_supported(const FrameDesc &d)
            d.rd_shift >= 0 && d.rd_shift < (1ll << 30);
 }
 
+#endif
 template <typename T, int NR, bool MN0, bool EPI, int WIDE, bool TBL, bool RING, bool CPLX = false, bool ILV = false>
 static hipError_t launch_fast_inst(T *Y, const T *X, const T *win, const T *tw, const R512FastArgs &a, hipStream_t s)
 {
@@ -746,6 +751,60 @@ static hipError_t launch_fast_inst(T *Y, const T *X, const T *win, const T *tw, 
     return hipGetLastError();
 }
 
+// Windows of 8 to 12, 14 and 15 rows of 32 samples (225 to 384 and 417 to 480 samples; 320 = 20 ms and 480 = 30 ms at 16 kHz): only the last row of
+// a lane that holds data is masked, and the first stage of the 16-point transform skips the empty rows.  Windows of 512 samples (rows = 17):
+// no row is masked.  These instantiations live in a
+// translation unit of their own (r512_fast_rows.hip: this file again with R512F_ROWS_TU = 1), hence in a code object of their own, which
+// the runtime brings to the device when one of them is first launched: with them in this one the first call of a process took 38 ms
+// instead of 24.  (8, 10, 15 and 17 with every flag; the counts in between without mean removal: they return hipErrorNotSupported then.)
+hipError_t launch_stft_r512_fast_rows(float *Y, const float *X, const float *win, const float *tw, const R512FastArgs &a, int rows, bool wide, bool mn0, bool epi, hipStream_t s);
+hipError_t launch_stft_r512_fast_rows(double *Y, const double *X, const double *win, const double *tw, const R512FastArgs &a, int rows, bool wide, bool mn0, bool epi, hipStream_t s);
+constexpr bool r512_fast_has_rows(int rows, bool mn0) { return rows == 8 || rows == 10 || rows == 15 || rows == 17 || (!mn0 && (rows == 9 || rows == 11 || rows == 12 || rows == 14)); }
+
+#if R512F_ROWS_TU
+template <typename T>
+static hipError_t launch_rows_any(T *Y, const T *X, const T *win, const T *tw, const R512FastArgs &a, int rows, bool wide, bool mn0, bool epi, hipStream_t s)
+{
+    constexpr bool RING = sizeof(T) == 4 && R512F_RING_F32;
+#define DSP_R512F(NR_, MN0_, EPI_) launch_fast_inst<T, NR_, MN0_, EPI_, 0, false, RING>(Y, X, win, tw, a, s)
+#define DSP_R512W(NR_, MN0_, EPI_) launch_fast_inst<T, NR_, MN0_, EPI_, 1, false, RING>(Y, X, win, tw, a, s)
+#define DSP_R512ROWS(NR_)                                                                                       \
+    if (rows == NR_ && wide) {                                                                                  \
+        if (mn0) { return epi ? DSP_R512W(NR_, true, true) : DSP_R512W(NR_, true, false); }                     \
+        return epi ? DSP_R512W(NR_, false, true) : DSP_R512W(NR_, false, false);                                \
+    }                                                                                                           \
+    if (rows == NR_) {                                                                                          \
+        if (mn0) { return epi ? DSP_R512F(NR_, true, true) : DSP_R512F(NR_, true, false); }                     \
+        return epi ? DSP_R512F(NR_, false, true) : DSP_R512F(NR_, false, false);                                \
+    }
+    DSP_R512ROWS(8)
+    DSP_R512ROWS(10)
+    DSP_R512ROWS(15)
+    DSP_R512ROWS(17)
+#undef DSP_R512ROWS
+#define DSP_R512ROWS(NR_)                                                                                       \
+    if (rows == NR_ && !mn0) {                                                                                  \
+        if (wide) { return epi ? DSP_R512W(NR_, false, true) : DSP_R512W(NR_, false, false); }                  \
+        return epi ? DSP_R512F(NR_, false, true) : DSP_R512F(NR_, false, false);                                \
+    }
+    DSP_R512ROWS(9)
+    DSP_R512ROWS(11)
+    DSP_R512ROWS(12)
+    DSP_R512ROWS(14)
+#undef DSP_R512ROWS
+#undef DSP_R512F
+#undef DSP_R512W
+    return hipErrorNotSupported;
+}
+hipError_t launch_stft_r512_fast_rows(float *Y, const float *X, const float *win, const float *tw, const R512FastArgs &a, int rows, bool wide, bool mn0, bool epi, hipStream_t s)
+{
+    return launch_rows_any<float>(Y, X, win, tw, a, rows, wide, mn0, epi, s);
+}
+hipError_t launch_stft_r512_fast_rows(double *Y, const double *X, const double *win, const double *tw, const R512FastArgs &a, int rows, bool wide, bool mn0, bool epi, hipStream_t s)
+{
+    return launch_rows_any<double>(Y, X, win, tw, a, rows, wide, mn0, epi, s);
+}
+#else
 template <typename T>
 static hipError_t launch_stft_r512_fast_one(T *Y, const T *X, const T *win, const T *tw, const FrameDesc &d, hipStream_t s);
 
@@ -822,43 +881,11 @@ static hipError_t launch_stft_r512_fast_one(T *Y, const T *X, const T *win, cons
         if (d.mn0) { return epi ? DSP_R512X(true, true) : DSP_R512X(true, false); }
         return epi ? DSP_R512X(false, true) : DSP_R512X(false, false);
     }
-    // L = 512 (the window covers all 16 rows: no row of a lane is ever masked; the 32 lane masks of the general form live in scalar
-    // registers that spill into the lanes of a vector register, about 90 instructions per step)
-    if (d.L == 512 && wide) {
-        if (d.mn0) { return epi ? DSP_R512W(17, true, true) : DSP_R512W(17, true, false); }
-        return epi ? DSP_R512W(17, false, true) : DSP_R512W(17, false, false);
-    }
-    if (d.L == 512) {
-        if (d.mn0) { return epi ? DSP_R512F(17, true, true) : DSP_R512F(17, true, false); }
-        return epi ? DSP_R512F(17, false, true) : DSP_R512F(17, false, false);
-    }
-    // other windows whose last rows are empty: 8 rows (225 to 256 samples), 10 (289 to 320: 20 ms at 16 kHz), 15 (449 to 480: 30 ms), and below the rest from 9 to 14.  Only the last
-    // row of a lane that holds data is masked then, and the first stage of the 16-point transform skips the empty rows.
-    const int rows = (d.L + 31) / 32;
-#define DSP_R512ROWS(NR_)                                                                                       \
-    if (rows == NR_ && wide) {                                                                                  \
-        if (d.mn0) { return epi ? DSP_R512W(NR_, true, true) : DSP_R512W(NR_, true, false); }                   \
-        return epi ? DSP_R512W(NR_, false, true) : DSP_R512W(NR_, false, false);                                \
-    }                                                                                                           \
-    if (rows == NR_) {                                                                                          \
-        if (d.mn0) { return epi ? DSP_R512F(NR_, true, true) : DSP_R512F(NR_, true, false); }                   \
-        return epi ? DSP_R512F(NR_, false, true) : DSP_R512F(NR_, false, false);                                \
-    }
-    DSP_R512ROWS(8)
-    DSP_R512ROWS(10)
-    DSP_R512ROWS(15)
-#undef DSP_R512ROWS
-    // (the row counts in between, without mean removal)
-#define DSP_R512ROWS(NR_)                                                                                       \
-    if (rows == NR_ && !d.mn0) {                                                                                \
-        if (wide) { return epi ? DSP_R512W(NR_, false, true) : DSP_R512W(NR_, false, false); }                  \
-        return epi ? DSP_R512F(NR_, false, true) : DSP_R512F(NR_, false, false);                                \
-    }
-    DSP_R512ROWS(9)
-    DSP_R512ROWS(11)
-    DSP_R512ROWS(12)
-    DSP_R512ROWS(14)
-#undef DSP_R512ROWS
+    // other windows whose last rows are empty, and L = 512, whose rows are never masked (17 stands for that: the 32 lane masks of the general
+    // form live in scalar registers that spill into the lanes of a vector register, about 90 instructions per step): the instantiations of
+    // r512_fast_rows.hip
+    const int rows = d.L == 512 ? 17 : (d.L + 31) / 32;
+    if (r512_fast_has_rows(rows, d.mn0)) { return launch_stft_r512_fast_rows(Y, X, win, tw, a, rows, wide, d.mn0, epi, s); }
     if (wide && nr13) {
         if (d.mn0) { return epi ? DSP_R512W(13, true, true) : DSP_R512W(13, true, false); }
         return epi ? DSP_R512W(13, false, true) : DSP_R512W(13, false, false);
@@ -953,5 +980,6 @@ template hipError_t launch_stft_r512_fast_cplx<double>(double *, const double *,
 
 template hipError_t launch_stft_r512_fast<float>(float *, const float *, const float *, const float *, const FrameDesc &, hipStream_t);
 template hipError_t launch_stft_r512_fast<double>(double *, const double *, const double *, const double *, const FrameDesc &, hipStream_t);
+#endif   // !R512F_ROWS_TU
 
 }  // namespace dsp

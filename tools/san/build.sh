@@ -8,7 +8,7 @@ HIPCC=/opt/rocm/bin/hipcc
 CLANG=/opt/rocm/lib/llvm/bin/clang++
 SAN="-Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined -Xarch_host -fno-sanitize-recover=undefined -Xarch_host -fno-omit-frame-pointer"
 mkdir -p $O
-for f in abi_core abi_stream abi_multi abi_unfused abi_exports generic_kernels r512_kernel r512_fast_kernel r512x_kernel r256_kernel r4096_kernel r8192_kernel wave_fft_kernel; do
+for f in abi_core abi_stream abi_multi abi_unfused abi_exports generic_kernels r512_kernel r512_fast_kernel r512_fast_rows r512x_kernel r256_kernel r4096_kernel r8192_kernel wave_fft_kernel; do
   ( $HIPCC -O3 -g1 -std=c++17 --offload-arch=gfx950 -fPIC -fno-slp-vectorize $SAN -c $R/dsp_amd/csrc/$f.hip -o $O/$f.o ) &
 done
 wait

@@ -3,7 +3,7 @@
 import sys
 sys.path.insert(0, '.')
 import numpy as np, torch, dsp_amd
-for (nfft, L, hop) in [(512, 512, 128), (512, 512, 256), (512, 480, 128), (512, 480, 160), (512, 320, 160), (512, 256, 128), (512, 300, 100), (1024, 1024, 220), (1024, 551, 220), (1024, 800, 200), (1024, 800, 320), (1024, 882, 441), (1024, 960, 480), (1024, 700, 220), (2048, 2048, 480), (2048, 1200, 480), (2048, 1102, 441), (2048, 1500, 512), (256, 256, 64), (256, 240, 64), (256, 240, 80), (256, 160, 80), (256, 200, 80), (128, 128, 32)]:
+for (nfft, L, hop) in [(512, 512, 128), (512, 512, 256), (512, 480, 128), (512, 480, 160), (512, 320, 160), (512, 256, 128), (512, 300, 100), (1024, 1024, 220), (1024, 551, 220), (1024, 800, 200), (1024, 800, 320), (1024, 882, 441), (1024, 960, 480), (1024, 700, 220), (2048, 2048, 480), (2048, 1200, 480), (2048, 1102, 441), (2048, 1500, 512), (4096, 4096, 1024), (4096, 4096, 960), (4096, 2400, 960), (4096, 3000, 1024), (256, 256, 64), (256, 240, 64), (256, 240, 80), (256, 160, 80), (256, 200, 80), (128, 128, 32)]:
     B, N = 8, 1 << 24
     x = torch.randn((B, N), device='cuda') * 0.1
     win = torch.from_numpy(dsp_amd.hann(L, np.float32)).cuda()

@@ -506,7 +506,15 @@ static hipError_t launch_r256_cl(T *Y, const T *X, const T *win, const T *tw, co
         }
         if (reach <= 1280) { return launch_r256_shape<T, CL, 16, 1280, true>(Y, X, win, tw, a, d, cplx, s); }
     } else {
-        if (reach <= 1024) { return launch_r256_shape<T, CL, 16, 1024, true>(Y, X, win, tw, a, d, cplx, s); }
+        if (reach <= 1024) {
+            if constexpr (CL == 8) {
+                const int rows = (d.L + 2 * CL - 1) / (2 * CL);
+                if (rows == 10) { return launch_r256_shape<T, CL, 10, 1024, true>(Y, X, win, tw, a, d, cplx, s); }
+                if (rows == 13) { return launch_r256_shape<T, CL, 13, 1024, true>(Y, X, win, tw, a, d, cplx, s); }
+                if (rows == 15) { return launch_r256_shape<T, CL, 15, 1024, true>(Y, X, win, tw, a, d, cplx, s); }
+            }
+            return launch_r256_shape<T, CL, 16, 1024, true>(Y, X, win, tw, a, d, cplx, s);
+        }
     }
     return launch_r256_shape<T, CL, 16, MAXS, true>(Y, X, win, tw, a, d, cplx, s);
 }

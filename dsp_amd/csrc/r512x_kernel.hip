@@ -821,7 +821,7 @@ static hipError_t launch_r512x_shape(T *Y, const T *X, const T *win, const T *tw
         return epi ? DSP_R512X(true, false, true) : DSP_R512X(true, false, false);
     }
     if (d.mn0) { return epi ? DSP_R512X(false, true, true) : DSP_R512X(false, true, false); }
-    if constexpr (Q == 2 && sizeof(T) == 4 && ALN) {
+    if constexpr (Q == 2 && ALN) {
         // windows of 8 to 15 rows of 64 samples (449 to 960 samples; 513-576: 25 ms at 22.05 kHz; 769-832: 25 ms at 32 kHz; 833-896: 20 ms at
         // 44.1 kHz; 897-960: 20 ms at 48 kHz): one masked row instead of 32 lane masks
         const int nk = (d.L + 63) / 64;

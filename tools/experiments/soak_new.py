@@ -1,5 +1,5 @@
 """Many launches of the forms added last (hops above 512, interleaved channels read in place, the float64 4096-point kernel, the
-8192-point kernel, the 2048-point kernel with its partner fetch by ds_bpermute), every result compared with the first by an
+8192-point kernel, the 2048-point kernel with its partner fetch by ds_bpermute, the forms for windows shorter than the transform), every result compared with the first by an
 exact checksum per signal (the 4096-point run form deals runs at run time: compared to 1e-6 / 1e-14 instead)."""
 import sys
 sys.path.insert(0, '.')
@@ -30,5 +30,12 @@ ok &= soak('nfft 2048', lambda: dsp_amd.stft_dev(x8, w2, 512, nfft=2048), 500)
 xd2 = xd[:, :1 << 22]
 w2d = torch.from_numpy(dsp_amd.hann(2048, np.float64)).cuda()
 ok &= soak('nfft 2048 float64', lambda: dsp_amd.stft_dev(xd2, w2d, 512, nfft=2048), 500)
+# windows shorter than the transform: the unmasked slot of the 2048-point kernel (zeros written behind the window once a span has landed),
+# the row-count instantiations of the 1024-, 512- and 256-point kernels
+for (nfft, L, hop) in ((2048, 1102, 441), (2048, 1201, 480), (1024, 551, 220), (512, 480, 160), (512, 512, 128), (256, 240, 80)):
+    wl = torch.from_numpy(dsp_amd.povey(L, np.float32)).cuda()
+    ok &= soak(f'nfft {nfft} L {L} hop {hop}', lambda: dsp_amd.stft_dev(x8, wl, hop, nfft=nfft), 500)
+wl = torch.from_numpy(dsp_amd.povey(1103, np.float64)).cuda()
+ok &= soak('nfft 2048 L 1103 hop 441 float64', lambda: dsp_amd.stft_dev(xd2, wl, 441, nfft=2048), 500)
 print('SOAK', 'OK' if ok else 'FAILED')
 sys.exit(0 if ok else 1)
